@@ -1,0 +1,143 @@
+/*
+ * svs_amd.h -- C ABI of the MI355X (gfx950) brute-force similarity backend for SVS.
+ *
+ * This is the drop-in boundary for the ONE hot path of Rhobota/svs v0.7.4: the
+ * cosine-similarity + top-k search inside KB.retrieve()/AsyncKB.retrieve().
+ * The reference has no FFI of its own (it is pure Python + NumPy), so each entry
+ * point below cites the reference lines it replaces; INTEGRATION.md shows the
+ * ctypes stub a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no exceptions / abort() cross this boundary;
+ *   - every function returns SVS_OK (0) or a negative svs_status; the message for
+ *     the calling thread's last failure is svs_last_error() (thread-local);
+ *   - status -> Python exception the host wrapper raises, matching the reference:
+ *       SVS_ERR_SHAPE   ValueError  (numpy: "shapes (N,D) and (d,) not aligned",
+ *                                    src/svs/kb.py:1623 with a wrong-sized query)
+ *       SVS_ERR_INVALID ValueError  (bad argument)
+ *       SVS_ERR_DEVICE  RuntimeError (HIP failure)     SVS_ERR_NOMEM MemoryError
+ *   - an index handle is reference counted: create() returns it with one
+ *     reference; search calls hold a reference for their duration, so release()
+ *     from _EmbeddingsMatrix.invalidate() (src/svs/kb.py:861-864) may race with
+ *     an in-flight AsyncKB search on an executor thread (src/svs/kb.py:1184-1190);
+ *   - all search entry points are re-entrant on one handle.
+ */
+#ifndef SVS_AMD_H
+#define SVS_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct svs_index svs_index;
+
+typedef enum svs_status {
+  SVS_OK = 0,
+  SVS_ERR_INVALID = -1,
+  SVS_ERR_SHAPE = -2,
+  SVS_ERR_DEVICE = -3,
+  SVS_ERR_NOMEM = -4,
+  SVS_ERR_UNSUPPORTED = -5
+} svs_status;
+
+/* element type of the HBM-resident corpus (the arithmetic stays f32-accumulate) */
+typedef enum svs_dtype {
+  SVS_DTYPE_F32 = 0, /* reference layout: np.zeros((n, m), float32), src/svs/kb.py:600 */
+  SVS_DTYPE_F16 = 1  /* extension for BASELINE.json configs[2]/[3]: rows rounded to f16 on upload */
+} svs_dtype;
+
+typedef struct svs_index_info_t {
+  int64_t n;          /* rows held by this handle (one shard)                 */
+  int32_t d;          /* logical dimension                                     */
+  int32_t ld;         /* padded row stride in elements (HBM layout)            */
+  int32_t dtype;      /* svs_dtype                                             */
+  int32_t device;     /* HIP device ordinal                                    */
+  int64_t row_offset; /* global row index of local row 0 (row sharding, 8(e))  */
+  int64_t hbm_bytes;  /* bytes of HBM held by the corpus                       */
+} svs_index_info_t;
+
+/* Stages timed with HIP events on the stream the kernels run on (bench.py roofline). */
+typedef struct svs_timing_t {
+  double score_ms_sum;  /* dominant kernel: query x corpus GEMV/GEMM            */
+  double select_ms_sum; /* top-k select + order kernels                          */
+  int64_t launches;     /* number of searches accumulated                        */
+} svs_timing_t;
+
+/* ---- library ------------------------------------------------------------- */
+const char* svs_version(void);
+const char* svs_last_error(void);
+/* Number of visible HIP devices (0 when none; never fails). */
+int32_t svs_device_count(void);
+
+/* ---- index lifetime: replaces the cached (embeddings_matrix, emb_id_lookup)
+ *      pair of _EmbeddingsMatrix, src/svs/kb.py:856-893 --------------------- */
+
+/* One pinned-staged H2D copy of a C-contiguous f32 (n, d) host matrix -- the
+ * array _Querier.build_embeddings_matrix returns (src/svs/kb.py:573-618) -- into
+ * HBM on `device`.  The library copies, never aliases: the caller keeps owning
+ * host_rows.  n == 0 or d == 0 is representable (search then reports
+ * SVS_ERR_SHAPE, like numpy on a (0,0) matrix).  row_offset is added to every
+ * returned row index (row-sharded corpora; 0 for a whole corpus). */
+int32_t svs_index_create(const float* host_rows, int64_t n, int32_t d, int32_t store_dtype,
+                         int32_t device, int64_t row_offset, svs_index** out);
+
+/* Same, from rows already in device memory on `device` (f32, row stride
+ * src_ld elements): synthetic corpora generated on the GPU, shards staged
+ * GPU->GPU.  Copies; does not alias. */
+int32_t svs_index_create_from_device(const float* dev_rows, int64_t n, int32_t d, int64_t src_ld,
+                                     int32_t store_dtype, int32_t device, int64_t row_offset,
+                                     svs_index** out);
+
+int32_t svs_index_retain(svs_index* idx);
+/* Drops one reference; HBM is freed when the last holder (including in-flight
+ * searches) lets go.  Called from invalidate(), src/svs/kb.py:861-864. */
+int32_t svs_index_release(svs_index* idx);
+int32_t svs_index_info(const svs_index* idx, svs_index_info_t* out);
+
+/* ---- search: replaces np.dot + get_top_k of superheavy(),
+ *      src/svs/kb.py:1622-1627 (sync) / :1184-1189 (async),
+ *      src/svs/util.py:190-203 ----------------------------------------------- */
+
+/* nq queries (f32, C-contiguous (nq, d), host memory).  Per query:
+ *   count = min(max(k, 0), n)            (src/svs/util.py:198-201)
+ *   out_scores[i*k .. i*k+count)  f32 dot products, descending
+ *   out_rows  [i*k .. i*k+count)  row_offset + local row; order is
+ *                                 (score desc, row desc)  (src/svs/util.py:203)
+ * Rows are ROW indices; the caller applies emb_id_lookup (src/svs/kb.py:1626).
+ * d != index d -> SVS_ERR_SHAPE.  Blocks until the results are in the output
+ * buffers.  The corpus is NOT re-normalised (vectors are validated unit-norm by
+ * the reference, src/svs/embeddings/util.py:26-41, so cosine == dot). */
+int32_t svs_index_search(svs_index* idx, const float* queries, int32_t nq, int32_t d, int32_t k,
+                         float* out_scores, int64_t* out_rows, int32_t* out_count);
+
+/* Device-resident variant for pipelines and the multi-GPU gather (8(e)): queries
+ * and outputs are device pointers on the index's device, work is enqueued on
+ * `hip_stream` (a hipStream_t; NULL = the default stream) and the call returns
+ * without synchronising.  Output layout as above with stride k; entries past
+ * count are filled with score = -inf, row = -1.  *out_count is written on the
+ * host immediately (it depends only on k and n). */
+int32_t svs_index_search_device(svs_index* idx, const float* dev_queries, int32_t nq, int32_t d,
+                                int32_t k, float* dev_out_scores, int64_t* dev_out_rows,
+                                int32_t* out_count, void* hip_stream);
+
+/* All scores of one query, f32 (n) to host: the raw `np.dot(M, q)` vector
+ * (src/svs/kb.py:1623) for callers that want it and for parity tests. */
+int32_t svs_index_scores(svs_index* idx, const float* query, int32_t d, float* out_scores);
+
+/* ---- measurement --------------------------------------------------------- */
+/* enable != 0: record HIP events around the score and select stages of every
+ * subsequent search on this handle and accumulate them. */
+int32_t svs_index_set_timing(svs_index* idx, int32_t enable);
+/* Waits for outstanding timed searches, returns the sums, and resets them. */
+int32_t svs_index_get_timing(svs_index* idx, svs_timing_t* out);
+
+/* Tuning knob for A/B runs (bench/profiling only): selects a kernel variant of
+ * the score stage; 0 = library default.  Returns SVS_ERR_INVALID if unknown. */
+int32_t svs_index_set_variant(svs_index* idx, int32_t variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVS_AMD_H */

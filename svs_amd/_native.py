@@ -1,0 +1,113 @@
+"""
+ctypes binding of libsvs_amd.so (include/svs_amd.h).
+
+The product path has NO CPU fallback: if the HIP library has not been built, or
+no MI355X is visible, the calls below raise.  (The numpy oracle lives under
+/oracle and is test infrastructure; nothing here imports it.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libsvs_amd.so")
+
+SVS_OK = 0
+SVS_ERR_INVALID = -1
+SVS_ERR_SHAPE = -2
+SVS_ERR_DEVICE = -3
+SVS_ERR_NOMEM = -4
+SVS_ERR_UNSUPPORTED = -5
+
+DTYPE_F32 = 0
+DTYPE_F16 = 1
+
+
+class IndexInfo(C.Structure):
+    _fields_ = [
+        ("n", C.c_int64),
+        ("d", C.c_int32),
+        ("ld", C.c_int32),
+        ("dtype", C.c_int32),
+        ("device", C.c_int32),
+        ("row_offset", C.c_int64),
+        ("hbm_bytes", C.c_int64),
+    ]
+
+
+class Timing(C.Structure):
+    _fields_ = [
+        ("score_ms_sum", C.c_double),
+        ("select_ms_sum", C.c_double),
+        ("launches", C.c_int64),
+    ]
+
+
+# every symbol include/svs_amd.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+SIGNATURES = {
+    "svs_version": (C.c_char_p, []),
+    "svs_last_error": (C.c_char_p, []),
+    "svs_device_count": (C.c_int32, []),
+    "svs_index_create": (C.c_int32, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.POINTER(_P)]),
+    "svs_index_create_from_device": (C.c_int32, [_P, C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.POINTER(_P)]),
+    "svs_index_retain": (C.c_int32, [_P]),
+    "svs_index_release": (C.c_int32, [_P]),
+    "svs_index_info": (C.c_int32, [_P, C.POINTER(IndexInfo)]),
+    "svs_index_search": (C.c_int32, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.POINTER(C.c_int32)]),
+    "svs_index_search_device": (C.c_int32, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.POINTER(C.c_int32), _P]),
+    "svs_index_scores": (C.c_int32, [_P, _P, C.c_int32, _P]),
+    "svs_index_set_timing": (C.c_int32, [_P, C.c_int32]),
+    "svs_index_get_timing": (C.c_int32, [_P, C.POINTER(Timing)]),
+    "svs_index_set_variant": (C.c_int32, [_P, C.c_int32]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load() -> C.CDLL:
+    """Loads the HIP library (once).  Raises RuntimeError when it is missing --
+    there is deliberately nothing to fall back to."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise RuntimeError(
+            f"svs_amd: HIP library not built ({_LIB_PATH}); run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C svs_amd/csrc`. There is no CPU fallback."
+        )
+    lib = C.CDLL(_LIB_PATH)  # CDLL releases the GIL around every call
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return (load().svs_last_error() or b"").decode("utf-8", "replace")
+
+
+def check(rc: int) -> None:
+    """Status -> the exception the reference raises at the same spot
+    (include/svs_amd.h, 'Conventions')."""
+    if rc == SVS_OK:
+        return
+    msg = last_error()
+    if rc in (SVS_ERR_SHAPE, SVS_ERR_INVALID):
+        raise ValueError(msg)
+    if rc == SVS_ERR_NOMEM:
+        raise MemoryError(msg)
+    if rc == SVS_ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise RuntimeError(msg)
+
+
+def device_count() -> int:
+    return int(load().svs_device_count())

@@ -1,0 +1,649 @@
+// C ABI of the MI355X similarity backend (see include/svs_amd.h).
+// Host side: HBM-resident corpus handle, per-call search contexts (stream +
+// scratch, so searches are re-entrant), launch sequencing of the score stage
+// (gemv_f32.h) and the top-k stage (select.h).  gfx950 only.
+#include "../../include/svs_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "gemv_f32.h"
+#include "select.h"
+
+namespace {
+
+using namespace svs;
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                       \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return fail(e_ == hipErrorOutOfMemory ? SVS_ERR_NOMEM : SVS_ERR_DEVICE, "%s: %s (%s:%d)", \
+                  #expr, hipGetErrorString(e_), __FILE__, __LINE__);                        \
+  } while (0)
+
+struct EvTriple {
+  hipEvent_t e0, e1, e2;
+};
+
+// One in-flight search: stream, device scratch, pinned staging.
+struct Ctx {
+  hipStream_t stream = nullptr;
+  float* q_dev = nullptr;       size_t q_cap = 0;        // floats
+  float* scores = nullptr;      size_t scores_cap = 0;   // floats
+  uint32_t* hist = nullptr;     size_t hist_cap = 0;     // queries
+  uint64_t* cand = nullptr;                               // counters live behind hist
+  uint64_t* keys = nullptr;     size_t keys_cap = 0;     // u64
+  float* out_s = nullptr;       int64_t* out_r = nullptr; size_t out_cap = 0;  // entries
+  float* q_pin = nullptr;       size_t q_pin_cap = 0;
+  float* out_s_pin = nullptr;   int64_t* out_r_pin = nullptr; size_t out_pin_cap = 0;
+  hipEvent_t busy = nullptr;    bool busy_valid = false;
+};
+
+}  // namespace
+
+struct svs_index {
+  std::atomic<int> refs{1};
+  int device = 0;
+  int64_t n = 0;
+  int d = 0, ld = 0, dtype = SVS_DTYPE_F32;
+  int64_t row_offset = 0;
+  void* rows = nullptr;
+  size_t bytes = 0;
+  int cu_count = 256;
+
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<Ctx*> free_ctx;
+  int n_ctx = 0;
+  static constexpr int kMaxCtx = 4;
+
+  std::atomic<int> timing{0};
+  std::atomic<int> variant{0};
+  std::vector<EvTriple> evs;  // guarded by mu
+};
+
+namespace {
+
+void ctx_destroy(Ctx* c) {
+  if (!c) return;
+  if (c->busy_valid) (void)hipEventSynchronize(c->busy);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  (void)hipFree(c->q_dev);
+  (void)hipFree(c->scores);
+  (void)hipFree(c->hist);
+  (void)hipFree(c->cand);
+  (void)hipFree(c->keys);
+  (void)hipFree(c->out_s);
+  (void)hipFree(c->out_r);
+  (void)hipHostFree(c->q_pin);
+  (void)hipHostFree(c->out_s_pin);
+  (void)hipHostFree(c->out_r_pin);
+  if (c->busy) (void)hipEventDestroy(c->busy);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+void index_destroy(svs_index* idx) {
+  (void)hipSetDevice(idx->device);
+  for (Ctx* c : idx->free_ctx) ctx_destroy(c);
+  for (auto& t : idx->evs) {
+    (void)hipEventDestroy(t.e0);
+    (void)hipEventDestroy(t.e1);
+    (void)hipEventDestroy(t.e2);
+  }
+  (void)hipFree(idx->rows);
+  delete idx;
+}
+
+int ctx_acquire(svs_index* idx, Ctx** out) {
+  std::unique_lock<std::mutex> lk(idx->mu);
+  for (;;) {
+    if (!idx->free_ctx.empty()) {
+      *out = idx->free_ctx.back();
+      idx->free_ctx.pop_back();
+      return SVS_OK;
+    }
+    if (idx->n_ctx < svs_index::kMaxCtx) {
+      idx->n_ctx++;
+      lk.unlock();
+      Ctx* c = new (std::nothrow) Ctx();
+      hipError_t e = c ? hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) : hipErrorOutOfMemory;
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&c->busy, hipEventDisableTiming);
+      if (e != hipSuccess) {
+        ctx_destroy(c);
+        lk.lock();
+        idx->n_ctx--;
+        return fail(SVS_ERR_DEVICE, "search context: %s", hipGetErrorString(e));
+      }
+      *out = c;
+      return SVS_OK;
+    }
+    idx->cv.wait(lk);
+  }
+}
+
+void ctx_release(svs_index* idx, Ctx* c) {
+  {
+    std::lock_guard<std::mutex> lk(idx->mu);
+    idx->free_ctx.push_back(c);
+  }
+  idx->cv.notify_one();
+}
+
+template <typename T>
+int grow_dev(T** p, size_t* cap, size_t need) {
+  if (need <= *cap) return SVS_OK;
+  if (*p) HIP_TRY(hipFree(*p));
+  *p = nullptr;
+  *cap = 0;
+  HIP_TRY(hipMalloc((void**)p, need * sizeof(T)));
+  *cap = need;
+  return SVS_OK;
+}
+
+int grow_out(Ctx* c, size_t need) {
+  if (need <= c->out_cap) return SVS_OK;
+  if (c->out_s) HIP_TRY(hipFree(c->out_s));
+  if (c->out_r) HIP_TRY(hipFree(c->out_r));
+  c->out_s = nullptr;
+  c->out_r = nullptr;
+  c->out_cap = 0;
+  HIP_TRY(hipMalloc((void**)&c->out_s, need * sizeof(float)));
+  HIP_TRY(hipMalloc((void**)&c->out_r, need * sizeof(int64_t)));
+  c->out_cap = need;
+  return SVS_OK;
+}
+
+int next_pow2_i64(int64_t v, int64_t* out) {
+  int64_t p = 2;
+  while (p < v) p <<= 1;
+  *out = p;
+  return 0;
+}
+
+// ---- score stage launch -----------------------------------------------------
+template <int NSTEP>
+void launch_rows(const svs_index* idx, const float* q, float* scores, hipStream_t st, int variant) {
+  const v4f* M = (const v4f*)idx->rows;
+  const v4f* qv = (const v4f*)q;
+  const int cus = idx->cu_count;
+  // variant: 0 default | 1: R=1 | 2: R=2 | 3: R=2 nt | 4: R=1 contiguous | 5: R=4
+  switch (variant) {
+    default:
+    case 0:
+    case 1: {
+      constexpr int R = 1, WPB = 4;
+      int64_t tiles = (idx->n + R - 1) / R;
+      int blocks = (int)std::min<int64_t>((tiles + WPB - 1) / WPB, (int64_t)cus * 5);
+      hipLaunchKernelGGL((gemv_f32_rows_kernel<NSTEP, R, WPB, false, false>), dim3(blocks), dim3(WPB * 64), 0, st, M, qv, scores, idx->n);
+      break;
+    }
+    case 2: {
+      constexpr int R = 2, WPB = 4;
+      int64_t tiles = (idx->n + R - 1) / R;
+      int blocks = (int)std::min<int64_t>((tiles + WPB - 1) / WPB, (int64_t)cus * 4);
+      hipLaunchKernelGGL((gemv_f32_rows_kernel<NSTEP, R, WPB, false, false>), dim3(blocks), dim3(WPB * 64), 0, st, M, qv, scores, idx->n);
+      break;
+    }
+    case 3: {
+      constexpr int R = 2, WPB = 4;
+      int64_t tiles = (idx->n + R - 1) / R;
+      int blocks = (int)std::min<int64_t>((tiles + WPB - 1) / WPB, (int64_t)cus * 4);
+      hipLaunchKernelGGL((gemv_f32_rows_kernel<NSTEP, R, WPB, true, false>), dim3(blocks), dim3(WPB * 64), 0, st, M, qv, scores, idx->n);
+      break;
+    }
+    case 4: {
+      constexpr int R = 1, WPB = 4;
+      int64_t tiles = (idx->n + R - 1) / R;
+      int blocks = (int)std::min<int64_t>((tiles + WPB - 1) / WPB, (int64_t)cus * 5);
+      hipLaunchKernelGGL((gemv_f32_rows_kernel<NSTEP, R, WPB, false, true>), dim3(blocks), dim3(WPB * 64), 0, st, M, qv, scores, idx->n);
+      break;
+    }
+    case 5: {
+      constexpr int R = 1, WPB = 4;
+      int64_t tiles = (idx->n + R - 1) / R;
+      int blocks = (int)std::min<int64_t>((tiles + WPB - 1) / WPB, (int64_t)cus * 5);
+      hipLaunchKernelGGL((gemv_f32_rows_kernel<NSTEP, R, WPB, true, false>), dim3(blocks), dim3(WPB * 64), 0, st, M, qv, scores, idx->n);
+      break;
+    }
+  }
+}
+
+template <int T>
+void launch_generic(const svs_index* idx, const float* q, float* scores, hipStream_t st) {
+  constexpr int RPW = 64 / T;
+  int64_t waves = (idx->n + RPW - 1) / RPW;
+  int blocks = (int)std::min<int64_t>((waves + 3) / 4, (int64_t)idx->cu_count * 8);
+  hipLaunchKernelGGL((gemv_f32_generic_kernel<T>), dim3(blocks), dim3(256), 0, st,
+                     (const v4f*)idx->rows, q, scores, idx->n, idx->d, idx->ld / 4);
+}
+
+// q: device, d floats (unpadded); scores: device, n floats
+int launch_scores(const svs_index* idx, const float* q, float* scores, hipStream_t st) {
+  if (idx->dtype != SVS_DTYPE_F32) return fail(SVS_ERR_UNSUPPORTED, "dtype %d not implemented yet", idx->dtype);
+  const int variant = idx->variant.load();
+  const bool q_aligned = (((uintptr_t)q) & 15) == 0;
+  if (idx->ld == idx->d && idx->ld % 256 == 0 && q_aligned) {
+    switch (idx->ld / 256) {
+      case 1: launch_rows<1>(idx, q, scores, st, variant); return SVS_OK;
+      case 2: launch_rows<2>(idx, q, scores, st, variant); return SVS_OK;
+      case 3: launch_rows<3>(idx, q, scores, st, variant); return SVS_OK;
+      case 4: launch_rows<4>(idx, q, scores, st, variant); return SVS_OK;
+      case 6: launch_rows<6>(idx, q, scores, st, variant); return SVS_OK;
+      case 8: launch_rows<8>(idx, q, scores, st, variant); return SVS_OK;
+      case 12: launch_rows<12>(idx, q, scores, st, variant); return SVS_OK;
+      default: break;
+    }
+  }
+  const int ld4 = idx->ld / 4;
+  if (ld4 <= 1) launch_generic<1>(idx, q, scores, st);
+  else if (ld4 <= 2) launch_generic<2>(idx, q, scores, st);
+  else if (ld4 <= 4) launch_generic<4>(idx, q, scores, st);
+  else if (ld4 <= 8) launch_generic<8>(idx, q, scores, st);
+  else if (ld4 <= 16) launch_generic<16>(idx, q, scores, st);
+  else if (ld4 <= 32) launch_generic<32>(idx, q, scores, st);
+  else launch_generic<64>(idx, q, scores, st);
+  return SVS_OK;
+}
+
+// ---- whole search on a stream; all pointers are device pointers --------------
+int enqueue_search(svs_index* idx, Ctx* c, const float* q_dev, int nq, int k, int count,
+                   float* out_s, int64_t* out_r, hipStream_t st) {
+  const int64_t n = idx->n;
+  int rc;
+  if ((rc = grow_dev(&c->scores, &c->scores_cap, (size_t)nq * (size_t)n)) != SVS_OK) return rc;
+
+  EvTriple ev{};
+  const bool timed = idx->timing.load() != 0;
+  if (timed) {
+    HIP_TRY(hipEventCreate(&ev.e0));
+    HIP_TRY(hipEventCreate(&ev.e1));
+    HIP_TRY(hipEventCreate(&ev.e2));
+    HIP_TRY(hipEventRecord(ev.e0, st));
+  }
+  for (int qi = 0; qi < nq; ++qi) {
+    rc = launch_scores(idx, q_dev + (size_t)qi * idx->d, c->scores + (size_t)qi * n, st);
+    if (rc != SVS_OK) return rc;
+  }
+  if (timed) HIP_TRY(hipEventRecord(ev.e1, st));
+
+  if (k > 0) {
+    if (n <= SORT_CAP) {
+      hipLaunchKernelGGL(select_sort_kernel, dim3(nq), dim3(SORT_THREADS), 0, st, c->scores, n, n, k,
+                         count, 1, (const uint32_t*)nullptr, (const uint64_t*)nullptr,
+                         (const SelCounters*)nullptr, idx->row_offset, out_s, out_r);
+    } else if (count <= SEL_KMAX) {
+      if ((size_t)nq > c->hist_cap) {
+        if (c->hist) HIP_TRY(hipFree(c->hist));
+        if (c->cand) HIP_TRY(hipFree(c->cand));
+        c->hist = nullptr; c->cand = nullptr; c->hist_cap = 0;
+        // hist and counters are contiguous so that one memset clears both
+        HIP_TRY(hipMalloc((void**)&c->hist, (size_t)nq * (3 * HIST_BINS * sizeof(uint32_t) + sizeof(SelCounters))));
+        HIP_TRY(hipMalloc((void**)&c->cand, (size_t)nq * SORT_CAP * sizeof(uint64_t)));
+        c->hist_cap = nq;
+      }
+      SelCounters* counters = (SelCounters*)(c->hist + (size_t)nq * 3 * HIST_BINS);
+      HIP_TRY(hipMemsetAsync(c->hist, 0, (size_t)nq * (3 * HIST_BINS * sizeof(uint32_t) + sizeof(SelCounters)), st));
+      int blocks = (int)std::min<int64_t>(std::max<int64_t>(n / 4096, 1), 512);
+      for (int pass = 0; pass < 3; ++pass)
+        hipLaunchKernelGGL(select_hist_kernel, dim3(blocks, nq), dim3(SEL_THREADS), 0, st, c->scores, n, n,
+                           (uint32_t)count, pass, c->hist);
+      hipLaunchKernelGGL(select_filter_kernel, dim3(blocks, nq), dim3(SEL_THREADS), 0, st, c->scores, n, n,
+                         (uint32_t)count, c->hist, c->cand, counters);
+      hipLaunchKernelGGL(select_sort_kernel, dim3(nq), dim3(SORT_THREADS), 0, st, c->scores, n, n, k, count, 0,
+                         c->hist, c->cand, counters, idx->row_offset, out_s, out_r);
+    } else {
+      int64_t npad;
+      next_pow2_i64(n, &npad);
+      if ((rc = grow_dev(&c->keys, &c->keys_cap, (size_t)nq * (size_t)npad)) != SVS_OK) return rc;
+      int gb = (int)std::min<int64_t>((npad + 255) / 256, 4096);
+      hipLaunchKernelGGL(keys_build_kernel, dim3(gb, nq), dim3(256), 0, st, c->scores, n, n, npad, c->keys);
+      const int64_t chunk = std::min<int64_t>(npad, SORT_CAP);
+      hipLaunchKernelGGL(bitonic_local_kernel, dim3((unsigned)(npad / chunk), nq), dim3(SORT_THREADS), 0, st, c->keys, npad, 0, 1);
+      for (int64_t size = 2 * (int64_t)SORT_CAP; size <= npad; size <<= 1) {
+        for (int64_t stride = size >> 1; stride >= SORT_CAP; stride >>= 1) {
+          int g2 = (int)std::min<int64_t>(((npad >> 1) + 255) / 256, 8192);
+          hipLaunchKernelGGL(bitonic_global_kernel, dim3(g2, nq), dim3(256), 0, st, c->keys, npad, size, stride);
+        }
+        hipLaunchKernelGGL(bitonic_local_kernel, dim3((unsigned)(npad / chunk), nq), dim3(SORT_THREADS), 0, st, c->keys, npad, size, 0);
+      }
+      int ge = std::min((k + 255) / 256, 1024);
+      hipLaunchKernelGGL(keys_emit_kernel, dim3(ge, nq), dim3(256), 0, st, c->keys, npad, k, count,
+                         idx->row_offset, out_s, out_r);
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  if (timed) {
+    HIP_TRY(hipEventRecord(ev.e2, st));
+    std::lock_guard<std::mutex> lk(idx->mu);
+    idx->evs.push_back(ev);
+  }
+  return SVS_OK;
+}
+
+int check_query_args(const svs_index* idx, const void* q, int nq, int d) {
+  if (!idx) return fail(SVS_ERR_INVALID, "null index");
+  if (nq < 0) return fail(SVS_ERR_INVALID, "nq must be >= 0");
+  if (d != idx->d || idx->n == 0 || idx->d == 0)
+    return fail(SVS_ERR_SHAPE, "shapes (%lld,%d) and (%d,) not aligned: %d (dim 1) != %d (dim 0)",
+                (long long)idx->n, idx->d, d, idx->d, d);
+  if (nq > 0 && !q) return fail(SVS_ERR_INVALID, "null queries");
+  return SVS_OK;
+}
+
+int create_common(int64_t n, int32_t d, int32_t store_dtype, int32_t device, int64_t row_offset,
+                  svs_index** out, svs_index** made) {
+  if (!out) return fail(SVS_ERR_INVALID, "null out");
+  *out = nullptr;
+  if (n < 0 || d < 0) return fail(SVS_ERR_INVALID, "negative shape (%lld, %d)", (long long)n, d);
+  if (store_dtype != SVS_DTYPE_F32) return fail(SVS_ERR_UNSUPPORTED, "store dtype %d not implemented yet", store_dtype);
+  if (n > 0xffffffffll) return fail(SVS_ERR_INVALID, "at most 2^32 rows per handle; shard the corpus");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(SVS_ERR_DEVICE, "no HIP device visible");
+  if (device < 0 || device >= ndev) return fail(SVS_ERR_INVALID, "device %d out of range [0,%d)", device, ndev);
+  HIP_TRY(hipSetDevice(device));
+  svs_index* idx = new (std::nothrow) svs_index();
+  if (!idx) return fail(SVS_ERR_NOMEM, "host allocation failed");
+  idx->device = device;
+  idx->n = n;
+  idx->d = d;
+  idx->ld = (d + 3) / 4 * 4;
+  idx->dtype = store_dtype;
+  idx->row_offset = row_offset;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) idx->cu_count = prop.multiProcessorCount;
+  idx->bytes = (size_t)n * (size_t)idx->ld * sizeof(float);
+  if (idx->bytes) {
+    hipError_t e = hipMalloc(&idx->rows, idx->bytes);
+    if (e != hipSuccess) {
+      delete idx;
+      return fail(e == hipErrorOutOfMemory ? SVS_ERR_NOMEM : SVS_ERR_DEVICE, "hipMalloc(%zu): %s", idx->bytes, hipGetErrorString(e));
+    }
+  }
+  *made = idx;
+  return SVS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* svs_version(void) { return "svs_amd 0.1.0 (gfx950)"; }
+const char* svs_last_error(void) { return g_err.c_str(); }
+
+int32_t svs_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int32_t svs_index_create(const float* host_rows, int64_t n, int32_t d, int32_t store_dtype,
+                         int32_t device, int64_t row_offset, svs_index** out) {
+  svs_index* idx = nullptr;
+  int rc = create_common(n, d, store_dtype, device, row_offset, out, &idx);
+  if (rc != SVS_OK) return rc;
+  if (idx->bytes) {
+    if (!host_rows) {
+      index_destroy(idx);
+      return fail(SVS_ERR_INVALID, "null host_rows");
+    }
+    // pinned double-buffered staging: host memcpy of chunk i+1 overlaps the DMA of chunk i
+    const size_t row_b = (size_t)d * sizeof(float), ld_b = (size_t)idx->ld * sizeof(float);
+    const size_t chunk_rows = std::max<size_t>(1, (32u << 20) / ld_b);
+    void* pin[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    hipStream_t st = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+      e = hipHostMalloc(&pin[i], chunk_rows * ld_b, hipHostMallocDefault);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
+    }
+    int b = 0;
+    for (size_t r0 = 0; r0 < (size_t)n && e == hipSuccess; r0 += chunk_rows, b ^= 1) {
+      const size_t rows = std::min(chunk_rows, (size_t)n - r0);
+      e = hipEventSynchronize(done[b]);
+      if (e != hipSuccess) break;
+      if (idx->ld == d) {
+        memcpy(pin[b], host_rows + r0 * (size_t)d, rows * row_b);
+      } else {
+        memset(pin[b], 0, rows * ld_b);
+        for (size_t r = 0; r < rows; ++r)
+          memcpy((char*)pin[b] + r * ld_b, host_rows + (r0 + r) * (size_t)d, row_b);
+      }
+      e = hipMemcpyAsync((char*)idx->rows + r0 * ld_b, pin[b], rows * ld_b, hipMemcpyHostToDevice, st);
+      if (e == hipSuccess) e = hipEventRecord(done[b], st);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    for (int i = 0; i < 2; ++i) {
+      if (done[i]) (void)hipEventDestroy(done[i]);
+      if (pin[i]) (void)hipHostFree(pin[i]);
+    }
+    if (st) (void)hipStreamDestroy(st);
+    if (e != hipSuccess) {
+      index_destroy(idx);
+      return fail(SVS_ERR_DEVICE, "corpus upload: %s", hipGetErrorString(e));
+    }
+  }
+  *out = idx;
+  return SVS_OK;
+}
+
+int32_t svs_index_create_from_device(const float* dev_rows, int64_t n, int32_t d, int64_t src_ld,
+                                     int32_t store_dtype, int32_t device, int64_t row_offset,
+                                     svs_index** out) {
+  svs_index* idx = nullptr;
+  int rc = create_common(n, d, store_dtype, device, row_offset, out, &idx);
+  if (rc != SVS_OK) return rc;
+  if (idx->bytes) {
+    if (!dev_rows || src_ld < d) {
+      index_destroy(idx);
+      return fail(SVS_ERR_INVALID, "bad device source (ptr %p, ld %lld)", (const void*)dev_rows, (long long)src_ld);
+    }
+    hipError_t e = hipSuccess;
+    if (idx->ld != d) e = hipMemset(idx->rows, 0, idx->bytes);
+    if (e == hipSuccess)
+      e = hipMemcpy2D(idx->rows, (size_t)idx->ld * sizeof(float), dev_rows, (size_t)src_ld * sizeof(float),
+                      (size_t)d * sizeof(float), (size_t)n, hipMemcpyDeviceToDevice);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+      index_destroy(idx);
+      return fail(SVS_ERR_DEVICE, "device corpus copy: %s", hipGetErrorString(e));
+    }
+  }
+  *out = idx;
+  return SVS_OK;
+}
+
+int32_t svs_index_retain(svs_index* idx) {
+  if (!idx) return fail(SVS_ERR_INVALID, "null index");
+  idx->refs.fetch_add(1);
+  return SVS_OK;
+}
+
+int32_t svs_index_release(svs_index* idx) {
+  if (!idx) return fail(SVS_ERR_INVALID, "null index");
+  if (idx->refs.fetch_sub(1) == 1) index_destroy(idx);
+  return SVS_OK;
+}
+
+int32_t svs_index_info(const svs_index* idx, svs_index_info_t* out) {
+  if (!idx || !out) return fail(SVS_ERR_INVALID, "null argument");
+  out->n = idx->n;
+  out->d = idx->d;
+  out->ld = idx->ld;
+  out->dtype = idx->dtype;
+  out->device = idx->device;
+  out->row_offset = idx->row_offset;
+  out->hbm_bytes = (int64_t)idx->bytes;
+  return SVS_OK;
+}
+
+int32_t svs_index_search(svs_index* idx, const float* queries, int32_t nq, int32_t d, int32_t k,
+                         float* out_scores, int64_t* out_rows, int32_t* out_count) {
+  int rc = check_query_args(idx, queries, nq, d);
+  if (rc != SVS_OK) return rc;
+  const int count = (int)std::min<int64_t>(std::max(k, 0), idx->n);
+  if (out_count) *out_count = count;
+  if (nq == 0 || count == 0) return SVS_OK;
+  if (!out_scores || !out_rows) return fail(SVS_ERR_INVALID, "null output");
+  svs_index_retain(idx);
+  struct Guard { svs_index* i; ~Guard() { svs_index_release(i); } } guard{idx};
+  HIP_TRY(hipSetDevice(idx->device));
+  Ctx* c = nullptr;
+  if ((rc = ctx_acquire(idx, &c)) != SVS_OK) return rc;
+  struct CtxGuard { svs_index* i; Ctx* c; ~CtxGuard() { ctx_release(i, c); } } cg{idx, c};
+  if (c->busy_valid) {
+    HIP_TRY(hipEventSynchronize(c->busy));
+    c->busy_valid = false;
+  }
+  const size_t qn = (size_t)nq * (size_t)d, on = (size_t)nq * (size_t)count;
+  if ((rc = grow_dev(&c->q_dev, &c->q_cap, qn)) != SVS_OK) return rc;
+  if ((rc = grow_out(c, on)) != SVS_OK) return rc;
+  if (qn > c->q_pin_cap) {
+    if (c->q_pin) HIP_TRY(hipHostFree(c->q_pin));
+    c->q_pin = nullptr; c->q_pin_cap = 0;
+    HIP_TRY(hipHostMalloc((void**)&c->q_pin, qn * sizeof(float), hipHostMallocDefault));
+    c->q_pin_cap = qn;
+  }
+  if (on > c->out_pin_cap) {
+    if (c->out_s_pin) HIP_TRY(hipHostFree(c->out_s_pin));
+    if (c->out_r_pin) HIP_TRY(hipHostFree(c->out_r_pin));
+    c->out_s_pin = nullptr; c->out_r_pin = nullptr; c->out_pin_cap = 0;
+    HIP_TRY(hipHostMalloc((void**)&c->out_s_pin, on * sizeof(float), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&c->out_r_pin, on * sizeof(int64_t), hipHostMallocDefault));
+    c->out_pin_cap = on;
+  }
+  memcpy(c->q_pin, queries, qn * sizeof(float));
+  HIP_TRY(hipMemcpyAsync(c->q_dev, c->q_pin, qn * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  if ((rc = enqueue_search(idx, c, c->q_dev, nq, count, count, c->out_s, c->out_r, c->stream)) != SVS_OK) {
+    (void)hipStreamSynchronize(c->stream);
+    return rc;
+  }
+  HIP_TRY(hipMemcpyAsync(c->out_s_pin, c->out_s, on * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->out_r_pin, c->out_r, on * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  // device layout has stride `count`; the caller's has stride k
+  for (int qi = 0; qi < nq; ++qi) {
+    memcpy(out_scores + (size_t)qi * k, c->out_s_pin + (size_t)qi * count, (size_t)count * sizeof(float));
+    memcpy(out_rows + (size_t)qi * k, c->out_r_pin + (size_t)qi * count, (size_t)count * sizeof(int64_t));
+  }
+  return SVS_OK;
+}
+
+int32_t svs_index_search_device(svs_index* idx, const float* dev_queries, int32_t nq, int32_t d,
+                                int32_t k, float* dev_out_scores, int64_t* dev_out_rows,
+                                int32_t* out_count, void* hip_stream) {
+  int rc = check_query_args(idx, dev_queries, nq, d);
+  if (rc != SVS_OK) return rc;
+  const int count = (int)std::min<int64_t>(std::max(k, 0), idx->n);
+  if (out_count) *out_count = count;
+  if (nq == 0 || k <= 0) return SVS_OK;
+  if (!dev_out_scores || !dev_out_rows) return fail(SVS_ERR_INVALID, "null output");
+  svs_index_retain(idx);
+  struct Guard { svs_index* i; ~Guard() { svs_index_release(i); } } guard{idx};
+  HIP_TRY(hipSetDevice(idx->device));
+  hipStream_t st = (hipStream_t)hip_stream;
+  Ctx* c = nullptr;
+  if ((rc = ctx_acquire(idx, &c)) != SVS_OK) return rc;
+  struct CtxGuard { svs_index* i; Ctx* c; ~CtxGuard() { ctx_release(i, c); } } cg{idx, c};
+  // scratch of this context may still be in use by an earlier enqueue on another stream
+  if (c->busy_valid) HIP_TRY(hipStreamWaitEvent(st, c->busy, 0));
+  const size_t need_scores = (size_t)nq * (size_t)idx->n;
+  if (need_scores > c->scores_cap && c->busy_valid) HIP_TRY(hipEventSynchronize(c->busy));
+  rc = enqueue_search(idx, c, dev_queries, nq, k, count, dev_out_scores, dev_out_rows, st);
+  HIP_TRY(hipEventRecord(c->busy, st));
+  c->busy_valid = true;
+  return rc;
+}
+
+int32_t svs_index_scores(svs_index* idx, const float* query, int32_t d, float* out_scores) {
+  int rc = check_query_args(idx, query, 1, d);
+  if (rc != SVS_OK) return rc;
+  if (!out_scores) return fail(SVS_ERR_INVALID, "null output");
+  svs_index_retain(idx);
+  struct Guard { svs_index* i; ~Guard() { svs_index_release(i); } } guard{idx};
+  HIP_TRY(hipSetDevice(idx->device));
+  Ctx* c = nullptr;
+  if ((rc = ctx_acquire(idx, &c)) != SVS_OK) return rc;
+  struct CtxGuard { svs_index* i; Ctx* c; ~CtxGuard() { ctx_release(i, c); } } cg{idx, c};
+  if (c->busy_valid) {
+    HIP_TRY(hipEventSynchronize(c->busy));
+    c->busy_valid = false;
+  }
+  if ((rc = grow_dev(&c->q_dev, &c->q_cap, (size_t)d)) != SVS_OK) return rc;
+  if ((rc = grow_dev(&c->scores, &c->scores_cap, (size_t)idx->n)) != SVS_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(c->q_dev, query, (size_t)d * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  if ((rc = launch_scores(idx, c->q_dev, c->scores, c->stream)) != SVS_OK) return rc;
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(out_scores, c->scores, (size_t)idx->n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return SVS_OK;
+}
+
+int32_t svs_index_set_timing(svs_index* idx, int32_t enable) {
+  if (!idx) return fail(SVS_ERR_INVALID, "null index");
+  idx->timing.store(enable ? 1 : 0);
+  return SVS_OK;
+}
+
+int32_t svs_index_get_timing(svs_index* idx, svs_timing_t* out) {
+  if (!idx || !out) return fail(SVS_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(idx->device));
+  std::vector<EvTriple> evs;
+  {
+    std::lock_guard<std::mutex> lk(idx->mu);
+    evs.swap(idx->evs);
+  }
+  out->score_ms_sum = 0;
+  out->select_ms_sum = 0;
+  out->launches = 0;
+  int rc = SVS_OK;
+  for (auto& t : evs) {
+    float a = 0, b = 0;
+    hipError_t e = hipEventSynchronize(t.e2);
+    if (e == hipSuccess) e = hipEventElapsedTime(&a, t.e0, t.e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&b, t.e1, t.e2);
+    if (e == hipSuccess) {
+      out->score_ms_sum += a;
+      out->select_ms_sum += b;
+      out->launches++;
+    } else {
+      rc = fail(SVS_ERR_DEVICE, "timing events: %s", hipGetErrorString(e));
+    }
+    (void)hipEventDestroy(t.e0);
+    (void)hipEventDestroy(t.e1);
+    (void)hipEventDestroy(t.e2);
+  }
+  return rc;
+}
+
+int32_t svs_index_set_variant(svs_index* idx, int32_t variant) {
+  if (!idx) return fail(SVS_ERR_INVALID, "null index");
+  if (variant < 0 || variant > 5) return fail(SVS_ERR_INVALID, "unknown variant %d", variant);
+  idx->variant.store(variant);
+  return SVS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,175 @@
+"""
+DeviceIndex: the HBM-resident embedding matrix plus the fused
+``np.dot(M, q)`` + ``get_top_k`` search of the reference's ``superheavy()``
+closure (reference src/svs/kb.py:1622-1627 / :1184-1189, src/svs/util.py:190-203).
+
+Thin host mirror over the C ABI (include/svs_amd.h).  All arithmetic happens in
+the HIP kernels; this module only marshals numpy buffers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import threading
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from . import _native
+
+
+class DeviceIndex:
+    """One shard of a corpus, resident in the HBM of one MI355X.
+
+    ``matrix`` is the array ``_Querier.build_embeddings_matrix`` returns
+    (reference src/svs/kb.py:600): float32, shape (N, D), C-contiguous.  It is
+    copied once (pinned staging -> HBM); the caller keeps ownership.
+    """
+
+    def __init__(self, matrix: Optional[np.ndarray], device: int = 0, row_offset: int = 0,
+                 *, _handle: Optional[int] = None):
+        self._lib = _native.load()
+        self._lock = threading.Lock()
+        self._h: Optional[int] = None
+        if _handle is not None:
+            self._h = _handle
+        else:
+            assert matrix is not None
+            m = np.asarray(matrix)
+            if m.ndim != 2:
+                raise ValueError(f"embeddings matrix must be 2-D, got shape {m.shape}")
+            if m.dtype != np.float32 or not m.flags["C_CONTIGUOUS"]:
+                m = np.ascontiguousarray(m, dtype=np.float32)
+            out = C.c_void_p()
+            _native.check(self._lib.svs_index_create(
+                m.ctypes.data_as(C.c_void_p), m.shape[0], m.shape[1], _native.DTYPE_F32,
+                int(device), int(row_offset), C.byref(out)))
+            self._h = out.value
+        info = _native.IndexInfo()
+        _native.check(self._lib.svs_index_info(self._h, C.byref(info)))
+        self.n, self.d, self.ld = int(info.n), int(info.d), int(info.ld)
+        self.device, self.row_offset = int(info.device), int(info.row_offset)
+        self.hbm_bytes = int(info.hbm_bytes)
+
+    @classmethod
+    def from_device_pointer(cls, ptr: int, n: int, d: int, src_ld: Optional[int] = None,
+                            device: int = 0, row_offset: int = 0) -> "DeviceIndex":
+        """Corpus rows already in device memory (f32): copies them into the
+        index's own HBM layout.  ``ptr`` is a raw device address (e.g.
+        ``tensor.data_ptr()``)."""
+        lib = _native.load()
+        out = C.c_void_p()
+        _native.check(lib.svs_index_create_from_device(
+            C.c_void_p(ptr), int(n), int(d), int(src_ld if src_ld is not None else d),
+            _native.DTYPE_F32, int(device), int(row_offset), C.byref(out)))
+        return cls(None, _handle=out.value)
+
+    # -- lifetime ---------------------------------------------------------
+    @property
+    def shape(self) -> Tuple[int, int]:
+        return (self.n, self.d)
+
+    def __len__(self) -> int:
+        return self.n
+
+    def _handle(self) -> int:
+        h = self._h
+        if h is None:
+            raise RuntimeError("DeviceIndex has been released")
+        return h
+
+    def release(self) -> None:
+        """Drops this object's reference; in-flight searches on other threads
+        keep the HBM alive until they finish (ref-counted in the library)."""
+        with self._lock:
+            h, self._h = self._h, None
+        if h is not None:
+            self._lib.svs_index_release(h)
+
+    close = release
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+    def _pinned_handle(self) -> int:
+        """retain() under the lock so a concurrent release() cannot free the
+        handle between reading it and entering the library."""
+        with self._lock:
+            h = self._handle()
+            self._lib.svs_index_retain(h)
+            return h
+
+    # -- search -----------------------------------------------------------
+    def search_batch(self, queries: np.ndarray, n: int) -> Tuple[np.ndarray, np.ndarray]:
+        """Top-n for each row of ``queries`` (nq, D).  Returns
+        (scores f32 (nq, count), rows i64 (nq, count)), count = min(max(n,0), N),
+        each row ordered (score desc, row desc)."""
+        assert isinstance(n, int)  # reference src/svs/util.py:197
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim != 2:
+            raise ValueError(f"queries must be 2-D, got shape {q.shape}")
+        nq, d = q.shape
+        k = max(n, 0)
+        scores = np.empty((nq, k), dtype=np.float32)
+        rows = np.empty((nq, k), dtype=np.int64)
+        count = C.c_int32(0)
+        h = self._pinned_handle()
+        try:
+            _native.check(self._lib.svs_index_search(
+                h, q.ctypes.data_as(C.c_void_p), nq, d, k,
+                scores.ctypes.data_as(C.c_void_p), rows.ctypes.data_as(C.c_void_p), C.byref(count)))
+        finally:
+            self._lib.svs_index_release(h)
+        c = count.value
+        return scores[:, :c], rows[:, :c]
+
+    def search(self, query_vec: np.ndarray, n: int) -> List[Tuple[float, int]]:
+        """``get_top_k(np.dot(M, query_vec), n)``: list of (score, row index),
+        python float / python int, as the reference returns them."""
+        assert isinstance(n, int)
+        q = np.asarray(query_vec, dtype=np.float32)
+        if q.ndim != 1:
+            raise ValueError(f"query must be 1-D, got shape {q.shape}")
+        s, r = self.search_batch(q[None, :], n)
+        return [(float(a), int(b)) for a, b in zip(s[0], r[0])]
+
+    def scores(self, query_vec: np.ndarray) -> np.ndarray:
+        """The raw ``np.dot(M, q)`` vector, f32 (N,)."""
+        q = np.ascontiguousarray(query_vec, dtype=np.float32)
+        if q.ndim != 1:
+            raise ValueError(f"query must be 1-D, got shape {q.shape}")
+        out = np.empty(self.n, dtype=np.float32)
+        h = self._pinned_handle()
+        try:
+            _native.check(self._lib.svs_index_scores(
+                h, q.ctypes.data_as(C.c_void_p), q.shape[0], out.ctypes.data_as(C.c_void_p)))
+        finally:
+            self._lib.svs_index_release(h)
+        return out
+
+    def search_device(self, q_ptr: int, nq: int, d: int, k: int, out_scores_ptr: int,
+                      out_rows_ptr: int, stream: int = 0) -> int:
+        """Device-pointer variant (no synchronisation): see svs_index_search_device."""
+        count = C.c_int32(0)
+        h = self._pinned_handle()
+        try:
+            _native.check(self._lib.svs_index_search_device(
+                h, C.c_void_p(q_ptr), int(nq), int(d), int(k), C.c_void_p(out_scores_ptr),
+                C.c_void_p(out_rows_ptr), C.byref(count), C.c_void_p(stream)))
+        finally:
+            self._lib.svs_index_release(h)
+        return count.value
+
+    # -- measurement ------------------------------------------------------
+    def set_timing(self, enable: bool) -> None:
+        _native.check(self._lib.svs_index_set_timing(self._handle(), 1 if enable else 0))
+
+    def get_timing(self) -> Tuple[float, float, int]:
+        t = _native.Timing()
+        _native.check(self._lib.svs_index_get_timing(self._handle(), C.byref(t)))
+        return float(t.score_ms_sum), float(t.select_ms_sum), int(t.launches)
+
+    def set_variant(self, variant: int) -> None:
+        _native.check(self._lib.svs_index_set_variant(self._handle(), int(variant)))

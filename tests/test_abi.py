@@ -1,0 +1,52 @@
+"""CPU: the C-ABI library loads and exports every symbol include/svs_amd.h
+declares (no compute calls -- there is no GPU in the build container)."""
+import os
+import re
+
+import pytest
+
+from svs_amd import _native
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    with open(os.path.join(ROOT, "include", "svs_amd.h")) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(svs_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_symbols_are_bound_and_exported():
+    syms = _declared_symbols()
+    assert len(syms) >= 14
+    lib = _native.load()
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/svs_amd.h but not exported"
+        assert s in _native.SIGNATURES, f"{s} has no ctypes signature"
+    assert sorted(_native.SIGNATURES) == syms
+
+
+def test_library_identifies_itself():
+    lib = _native.load()
+    assert b"gfx950" in lib.svs_version()
+    assert _native.device_count() >= 0
+
+
+def test_product_path_fails_loudly_without_gpu():
+    """No CPU fallback: constructing an index without a device raises."""
+    import numpy as np
+    from svs_amd import DeviceIndex
+    if _native.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(RuntimeError):
+        DeviceIndex(np.zeros((4, 4), dtype=np.float32))
+
+
+def test_product_code_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "svs_amd")
+    for dp, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                with open(os.path.join(dp, fn)) as f:
+                    src = f.read()
+                assert "import oracle" not in src and "from oracle" not in src and "svs_oracle" not in src, fn

@@ -1,0 +1,220 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the golden vectors
+recorded from the reference and against the numpy oracle on the same inputs."""
+import json
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from compare import assert_topk_parity
+from oracle import svs_oracle as oracle
+from synth import corpus_and_query
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _load(name):
+    with open(os.path.join(GOLD, name)) as f:
+        return json.load(f)
+
+
+def _index(m):
+    from svs_amd import DeviceIndex
+    return DeviceIndex(m)
+
+
+# ---- A4 through the device: a (N, 1) corpus with q = [1.0] makes score == value
+def test_get_top_k_golden_cases_through_hip(gpu):
+    g = _load("topk_cases.json")
+    ran = 0
+    for c in g["cases"]:
+        if c["dtype"] != "float32" or len(c["scores"]) == 0:
+            continue
+        arr = np.array(c["scores"], dtype=np.float32)
+        idx = _index(arr[:, None])
+        got = idx.search(np.array([1.0], dtype=np.float32), c["k"])
+        assert [[s, i] for s, i in got] == c["expected"], c["note"]
+        idx.release()
+        ran += 1
+    assert ran > 30
+
+
+def test_get_top_k_boundary_ties(gpu):
+    for c in _load("topk_cases.json")["boundary_ties"]:
+        arr = np.array(c["scores"], dtype=np.float32)
+        idx = _index(arr[:, None])
+        got = idx.search(np.array([1.0], dtype=np.float32), c["k"])
+        assert [s for s, _ in got] == c["expected_scores"]
+        # our documented rule at a boundary tie: the largest rows win
+        assert got == oracle.total_order_top_k(arr, c["k"])
+        idx.release()
+
+
+@pytest.mark.parametrize("case", _load("search_cases.json")["cases"],
+                         ids=lambda c: f'{c["kind"]}-{c["n"]}x{c["d"]}-k{c["k"]}')
+def test_search_golden(gpu, case):
+    m, qs = corpus_and_query(case["kind"], case["seed"], case["n"], case["d"], case["nq"])
+    idx = _index(m)
+    assert idx.shape == (case["n"], case["d"])
+    swaps = 0
+    for qi, q in enumerate(qs):
+        got = idx.search(q, case["k"])
+        truth = oracle.cpu_scores_f64(m, q)
+        swaps += assert_topk_parity([s for s, _ in got], [i for _, i in got],
+                                    case["scores"][qi], case["rows"][qi], truth,
+                                    label=f'{case["note"]} q{qi}')
+        gap = case["min_adjacent_gap_f64"][qi]
+        if gap is not None and gap > 2e-6:
+            assert [i for _, i in got] == case["rows"][qi]  # well separated: bit-exact indices
+    # batch entry == loop of single queries
+    bs, br = idx.search_batch(qs, case["k"])
+    for qi, q in enumerate(qs):
+        got = idx.search(q, case["k"])
+        assert [float(x) for x in bs[qi]] == [s for s, _ in got]
+        assert [int(x) for x in br[qi]] == [i for _, i in got]
+    idx.release()
+    print(f"near-tie swaps vs reference: {swaps}")
+
+
+def test_scores_vector_matches_numpy(gpu):
+    m, qs = corpus_and_query("gaussian", 5, 3000, 1536, 1)
+    idx = _index(m)
+    got = idx.scores(qs[0])
+    exp = oracle.cpu_scores(m, qs[0])
+    assert got.dtype == np.float32 and got.shape == exp.shape
+    assert np.max(np.abs(got.astype(np.float64) - exp)) <= 1e-5
+    truth = oracle.cpu_scores_f64(m, qs[0])
+    # our f32 summation must be at least as close to f64 truth as 5e-7
+    assert np.max(np.abs(got - truth)) < 5e-7
+    idx.release()
+
+
+@pytest.mark.parametrize("n,d", [(1, 1), (5, 2), (63, 5), (64, 7), (65, 12), (257, 33), (1000, 255),
+                                 (1000, 257), (513, 512), (300, 1024), (100, 2048), (50, 4096), (40, 1280)])
+def test_odd_shapes_against_oracle(gpu, n, d):
+    m, qs = corpus_and_query("gaussian", 100 + n + d, n, d, 2)
+    idx = _index(m)
+    for q in qs:
+        for k in (1, 7, n, n + 3):
+            got = idx.search(q, k)
+            exp = oracle.cpu_search(m, q, k)
+            assert_topk_parity([s for s, _ in got], [i for _, i in got],
+                               [s for s, _ in exp], [i for _, i in exp],
+                               oracle.cpu_scores_f64(m, q), label=f"{n}x{d} k={k}")
+    idx.release()
+
+
+def test_full_ranking_path(gpu):
+    """k > 1024 goes through the global bitonic sort; the reference's 'rank the
+    whole KB' call (n = 10,548, examples/dad_jokes)."""
+    m, qs = corpus_and_query("gaussian", 77, 10548, 256, 1)
+    idx = _index(m)
+    for k in (1025, 5000, 10548, 20000):
+        got = idx.search(qs[0], k)
+        exp = oracle.cpu_search(m, qs[0], k)
+        assert len(got) == min(k, 10548)
+        assert_topk_parity([s for s, _ in got], [i for _, i in got],
+                           [s for s, _ in exp], [i for _, i in exp],
+                           oracle.cpu_scores_f64(m, qs[0]), label=f"full ranking k={k}")
+    idx.release()
+
+
+def test_select_paths_agree(gpu):
+    """path A (radix select, k <= 1024) and path B (full sort) must produce the
+    same prefix on the same scores."""
+    rng = np.random.default_rng(3)
+    vals = rng.standard_normal(70000).astype(np.float32)
+    idx = _index(vals[:, None])
+    q = np.array([1.0], dtype=np.float32)
+    a = idx.search(q, 1024)
+    b = idx.search(q, 1500)
+    assert a == b[:1024]
+    assert a == oracle.total_order_top_k(vals, 1024)
+    idx.release()
+
+
+def test_mass_ties(gpu):
+    q = np.array([1.0], dtype=np.float32)
+    # every score identical: winners are the largest rows (documented rule)
+    eq = np.full(20000, 0.25, dtype=np.float32)
+    idx = _index(eq[:, None])
+    assert idx.search(q, 5) == [(0.25, r) for r in (19999, 19998, 19997, 19996, 19995)]
+    assert idx.search(q, 1000) == oracle.total_order_top_k(eq, 1000)
+    idx.release()
+    # 6000 ties straddling the k-th place (more than the candidate buffer holds)
+    rng = np.random.default_rng(4)
+    v = rng.standard_normal(50000).astype(np.float32) * 0.1
+    tie_rows = rng.choice(50000, 6000, replace=False)
+    v[tie_rows] = 0.9
+    v[rng.choice(np.setdiff1d(np.arange(50000), tie_rows), 40, replace=False)] = 1.5
+    idx = _index(v[:, None])
+    for k in (10, 41, 100, 1024):
+        assert idx.search(q, k) == oracle.total_order_top_k(v, k), k
+    idx.release()
+    # negative zero and positive zero tie (python: -0.0 == 0.0), order by row
+    z = np.array([0.0, -0.0, 0.0, -0.0, -1.0], dtype=np.float32)
+    idx = _index(z[:, None])
+    got = idx.search(q, 4)
+    assert [i for _, i in got] == [3, 2, 1, 0] and all(s == 0.0 for s, _ in got)
+    idx.release()
+
+
+def test_argument_semantics(gpu):
+    from svs_amd import DeviceIndex
+    m, qs = corpus_and_query("gaussian", 9, 100, 8, 1)
+    idx = DeviceIndex(m)
+    assert idx.search(qs[0], 0) == []
+    assert idx.search(qs[0], -3) == []
+    assert len(idx.search(qs[0], 1000)) == 100
+    with pytest.raises(ValueError):       # numpy: shapes (100,8) and (7,) not aligned
+        idx.search(qs[0][:7], 3)
+    with pytest.raises(AssertionError):   # reference asserts isinstance(top_k, int)
+        idx.search(qs[0], np.int64(3))
+    idx.release()
+    with pytest.raises(RuntimeError):
+        idx.search(qs[0], 3)
+    # empty table -> (0, 0) matrix -> the reference's retrieve() raises ValueError
+    empty = DeviceIndex(np.zeros((0, 0), dtype=np.float32))
+    with pytest.raises(ValueError):
+        empty.search(np.array([1.0, 0.0, 0.0], dtype=np.float32), 1)
+    empty.release()
+
+
+def test_row_offset(gpu):
+    from svs_amd import DeviceIndex
+    m, qs = corpus_and_query("gaussian", 10, 5000, 64, 1)
+    a = DeviceIndex(m)
+    b = DeviceIndex(m, row_offset=1_000_000_000_000)
+    ra, rb = a.search(qs[0], 10), b.search(qs[0], 10)
+    assert [(s, i + 1_000_000_000_000) for s, i in ra] == rb
+    a.release(); b.release()
+
+
+def test_concurrent_searches_and_release(gpu):
+    """AsyncKB runs superheavy() on executor threads outside its lock
+    (reference src/svs/kb.py:1184-1190) and invalidate() can race with them."""
+    m, qs = corpus_and_query("gaussian", 11, 40000, 256, 8)
+    idx = _index(m)
+    expected = [idx.search(q, 50) for q in qs]
+    errors = []
+
+    def worker(t):
+        try:
+            for it in range(20):
+                qi = (t + it) % len(qs)
+                assert idx.search(qs[qi], 50) == expected[qi]
+        except RuntimeError as e:   # released underneath us: allowed, but only this error
+            assert "released" in str(e)
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for t in ts:
+        t.start()
+    ts[0].join()
+    idx.release()   # in-flight searches keep the HBM alive
+    for t in ts:
+        t.join()
+    assert not errors, errors
