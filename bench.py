@@ -1,0 +1,263 @@
+#!/usr/bin/env python3
+"""
+bench.py -- headline benchmark of the svs_amd hot path on MI355X.
+
+Metric (BASELINE.json): queries/sec + p50 latency, cosine top-100 over
+1M x 1536 fp32.  One "step" = one pass of the hot path over one batch of
+synthetic input = ONE single-query search (score stage + top-k) over the whole
+corpus, inputs already resident in HBM.
+
+  python bench.py --gpus 1 --steps 200 --warmup 20
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+      --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
+
+N > 1: the 1M-row corpus is row-sharded; every rank scores its
+shard for every query, local top-k lists are exchanged with one RCCL all-gather
+per query and merged on rank 0 (strong scaling: total work is fixed).
+`--scaling weak` instead keeps --rows rows PER GPU.
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task notes):
+value = whole-job queries/s; roofline = algorithmic corpus bytes per launch of
+the dominant kernel / its HIP-event-measured duration; cpu_baseline = the numpy
+restatement of the reference path (oracle/) timed on this host's cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def gen_rows(torch, dev, seed, lo, hi, d, block=62500):
+    """Rows [lo, hi) of the synthetic unit-norm Gaussian corpus; block-seeded so
+    the content of a row does not depend on how the corpus is sharded."""
+    out = torch.empty((hi - lo, d), device=dev, dtype=torch.float32)
+    b0, b1 = lo // block, (hi + block - 1) // block
+    for b in range(b0, b1):
+        g = torch.Generator(device=dev)
+        g.manual_seed(seed * 1_000_003 + b)
+        x = torch.randn((block, d), device=dev, dtype=torch.float32, generator=g)
+        x /= x.norm(dim=1, keepdim=True)
+        s, e = max(lo, b * block), min(hi, (b + 1) * block)
+        out[s - lo:e - lo] = x[s - b * block:e - b * block]
+        del x
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--rows", type=int, default=1_000_000)
+    ap.add_argument("--dim", type=int, default=1536)
+    ap.add_argument("--k", type=int, default=100)
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=20)
+    ap.add_argument("--latency-iters", type=int, default=200)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from svs_amd import DeviceIndex
+    from svs_amd.sharded import merge_topk, shard_bounds
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    d, k, K, W = args.dim, args.k, args.steps, args.warmup
+    if args.scaling == "strong":
+        n_total = args.rows
+        lo, hi = shard_bounds(n_total, world, rank)
+    else:
+        n_total = args.rows * world
+        lo, hi = rank * args.rows, (rank + 1) * args.rows
+    n_local = hi - lo
+
+    # ---- synthetic corpus straight into HBM, then into the index's own layout
+    rows = gen_rows(torch, dev, args.seed, lo, hi, d)
+    torch.cuda.synchronize()
+    idx = DeviceIndex.from_device_pointer(rows.data_ptr(), n_local, d, device=local_rank, row_offset=lo)
+    if args.variant:
+        idx.set_variant(args.variant)
+    keep_rows_for_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    if not keep_rows_for_cpu:
+        del rows
+        torch.cuda.empty_cache()
+
+    # ---- queries: K + W distinct unit vectors, identical on every rank
+    g = torch.Generator(device=dev)
+    g.manual_seed(args.seed + 77)
+    queries = torch.randn((K + W, d), device=dev, dtype=torch.float32, generator=g)
+    queries /= queries.norm(dim=1, keepdim=True)
+
+    # per-step output record: [k f32 scores | pad | k i64 rows], gathered as bytes
+    s_bytes = (k * 4 + 7) // 8 * 8
+    rec = s_bytes + k * 8
+    local = torch.zeros((K + W, rec), device=dev, dtype=torch.uint8)
+    gathered = torch.zeros((K + W, world, rec), device=dev, dtype=torch.uint8) if world > 1 else None
+    stream = torch.cuda.current_stream().cuda_stream
+    count = min(k, n_local)
+
+    def step(i):
+        base = local[i].data_ptr()
+        idx.search_device(queries[i].data_ptr(), 1, d, k, base, base + s_bytes, stream)
+        if world > 1:
+            return dist.all_gather_into_tensor(gathered[i].view(-1), local[i], async_op=True)
+        return None
+
+    def finish(works, i0, i1):
+        """Wait for the exchanges and merge on rank 0 (host merge, H1)."""
+        for w in works:
+            if w is not None:
+                w.wait()
+        torch.cuda.synchronize()
+        if rank != 0:
+            return None
+        buf = (gathered[i0:i1] if world > 1 else local[i0:i1].unsqueeze(1)).cpu().numpy()
+        res = []
+        for j in range(i1 - i0):
+            sc = np.ascontiguousarray(buf[j, :, : k * 4]).view(np.float32).reshape(world, k)
+            rw = np.ascontiguousarray(buf[j, :, s_bytes:]).view(np.int64).reshape(world, k)
+            res.append(merge_topk(sc, rw, min(k, n_total)) if world > 1 else (sc[0, :count], rw[0, :count]))
+        return res
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    # ---- warmup (untimed)
+    finish([step(i) for i in range(W)], 0, W)
+    barrier()
+    torch.cuda.synchronize()
+
+    # ---- timed region: exactly K steps
+    idx.set_timing(True)
+    t0 = time.perf_counter()
+    works = [step(W + i) for i in range(K)]
+    results = finish(works, W, W + K)
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    score_ms, select_ms, launches = idx.get_timing()
+    idx.set_timing(False)
+
+    elapsed = t1 - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- p50 latency at the C-ABI boundary (host buffers in, results out, synced)
+    lat_ms = None
+    if world == 1:
+        qh = queries[: min(args.latency_iters, K + W)].cpu().numpy()
+        lats = []
+        for q in qh:
+            a = time.perf_counter()
+            idx.search(q, k)
+            lats.append((time.perf_counter() - a) * 1e3)
+        lat_ms = float(np.median(lats))
+
+    out = None
+    if rank == 0:
+        kernel_ms = score_ms / max(launches, 1)
+        alg_bytes = float(n_local) * d * 4
+        achieved = alg_bytes / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0
+        out = {
+            "metric": "queries/sec, cosine top-%d over %dx%d fp32, single query" % (k, n_total, d),
+            "value": K / elapsed,
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": elapsed / K * 1e3,
+            "higher_is_better": True,
+            "scaling": args.scaling,
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE.json configs[1]: %d docs x dim %d fp32, top-%d, single query, "
+                            "HBM-resident GEMV + top-k%s" % (n_total, d, k, "" if world == 1 else ", row-sharded over %d GPUs + RCCL all-gather + host merge" % world),
+                "rows_per_gpu": n_local, "dim": d, "k": k, "queries_per_step": 1,
+                "corpus": "unit-norm gaussian, seed %d, generated on device" % args.seed,
+                "variant": args.variant,
+            },
+            "p50_latency_ms": lat_ms,
+            "stage_ms": {"score": kernel_ms, "select": select_ms / max(launches, 1)},
+            "roofline": {
+                "bound": "hbm", "kernel": "gemv_f32 score stage",
+                "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK, "traffic": None,
+                "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": launches,
+                "avg_launch_ms": kernel_ms,
+            },
+        }
+
+    # ---- CPU baseline: the numpy restatement of the reference path, this host's cores
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import svs_oracle as oracle  # cpu_baseline leg only (checker + baseline)
+        m_host = rows.cpu().numpy()
+        del rows
+        torch.cuda.empty_cache()
+        qh = queries[W:W + 3 + args.cpu_iters].cpu().numpy()
+        for q in qh[:3]:
+            oracle.cpu_search(m_host, q, k)
+        ts = []
+        for q in qh[3:3 + args.cpu_iters]:
+            a = time.perf_counter()
+            oracle.cpu_search(m_host, q, k)
+            ts.append(time.perf_counter() - a)
+        p50 = float(np.median(ts))
+        # parity spot check of the timed results against the oracle (not timed)
+        mism = 0
+        for j in range(min(8, K)):
+            exp = oracle.cpu_search(m_host, queries[W + j].cpu().numpy(), k)
+            got_s, got_r = results[j]
+            if [int(x) for x in got_r] != [i for _, i in exp] or \
+                    max(abs(float(a) - b) for a, (b, _) in zip(got_s, exp)) > 1e-5:
+                mism += 1
+        try:
+            import threadpoolctl
+            thr = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [1])
+        except Exception:
+            thr = os.cpu_count()
+        try:
+            thr = min(int(thr), len(os.sched_getaffinity(0)))
+        except Exception:
+            pass
+        out["cpu_baseline"] = {
+            "value": 1.0 / p50, "unit": "queries/s", "cores": int(thr), "kind": "port",
+            "sample": "full %dx%d corpus, %d queries after 3 warm-ups, numpy %s np.dot + argpartition + sort (oracle/svs_oracle.py); p50 %.2f ms, min %.2f ms"
+                      % (n_total, d, len(ts), np.__version__, p50 * 1e3, min(ts) * 1e3),
+        }
+        out["parity_spot_check"] = {"queries": min(8, K), "mismatches": mism}
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    idx.release()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

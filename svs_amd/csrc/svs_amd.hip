@@ -184,51 +184,40 @@ int next_pow2_i64(int64_t v, int64_t* out) {
 }
 
 // ---- score stage launch -----------------------------------------------------
+template <int NSTEP, int R, int WPB, bool NT>
+void launch_oneshot(const svs_index* idx, const float* q, float* scores, hipStream_t st) {
+  const int64_t rows_per_block = (int64_t)R * WPB;
+  const int64_t blocks = (idx->n + rows_per_block - 1) / rows_per_block;
+  hipLaunchKernelGGL((gemv_f32_oneshot_kernel<NSTEP, R, WPB, NT, false>), dim3((unsigned)blocks), dim3(WPB * 64), 0, st,
+                     (const v4f*)idx->rows, (const v4f*)q, scores, idx->n);
+}
+
+template <int NSTEP, int R, bool NT>
+void launch_persistent(const svs_index* idx, const float* q, float* scores, hipStream_t st) {
+  constexpr int WPB = 4;
+  const int64_t tiles = (idx->n + R - 1) / R;
+  const int blocks = (int)std::min<int64_t>((tiles + WPB - 1) / WPB, (int64_t)idx->cu_count * 4);
+  hipLaunchKernelGGL((gemv_f32_rows_kernel<NSTEP, R, WPB, NT, false>), dim3(blocks), dim3(WPB * 64), 0, st,
+                     (const v4f*)idx->rows, (const v4f*)q, scores, idx->n);
+}
+
+// Default geometry per row length (measured at NSTEP = 6: one-shot, 16-wave
+// workgroups, one row per wave, nontemporal loads: 7.2 TB/s on MI355X).
+// Short rows take several rows per wave so a wave still has >= 4 KiB in flight.
 template <int NSTEP>
 void launch_rows(const svs_index* idx, const float* q, float* scores, hipStream_t st, int variant) {
-  const v4f* M = (const v4f*)idx->rows;
-  const v4f* qv = (const v4f*)q;
-  const int cus = idx->cu_count;
-  // variant: 0 default | 1: R=1 | 2: R=2 | 3: R=2 nt | 4: R=1 contiguous | 5: R=4
   switch (variant) {
-    default:
-    case 0:
-    case 1: {
-      constexpr int R = 1, WPB = 4;
-      int64_t tiles = (idx->n + R - 1) / R;
-      int blocks = (int)std::min<int64_t>((tiles + WPB - 1) / WPB, (int64_t)cus * 5);
-      hipLaunchKernelGGL((gemv_f32_rows_kernel<NSTEP, R, WPB, false, false>), dim3(blocks), dim3(WPB * 64), 0, st, M, qv, scores, idx->n);
-      break;
-    }
-    case 2: {
-      constexpr int R = 2, WPB = 4;
-      int64_t tiles = (idx->n + R - 1) / R;
-      int blocks = (int)std::min<int64_t>((tiles + WPB - 1) / WPB, (int64_t)cus * 4);
-      hipLaunchKernelGGL((gemv_f32_rows_kernel<NSTEP, R, WPB, false, false>), dim3(blocks), dim3(WPB * 64), 0, st, M, qv, scores, idx->n);
-      break;
-    }
-    case 3: {
-      constexpr int R = 2, WPB = 4;
-      int64_t tiles = (idx->n + R - 1) / R;
-      int blocks = (int)std::min<int64_t>((tiles + WPB - 1) / WPB, (int64_t)cus * 4);
-      hipLaunchKernelGGL((gemv_f32_rows_kernel<NSTEP, R, WPB, true, false>), dim3(blocks), dim3(WPB * 64), 0, st, M, qv, scores, idx->n);
-      break;
-    }
-    case 4: {
-      constexpr int R = 1, WPB = 4;
-      int64_t tiles = (idx->n + R - 1) / R;
-      int blocks = (int)std::min<int64_t>((tiles + WPB - 1) / WPB, (int64_t)cus * 5);
-      hipLaunchKernelGGL((gemv_f32_rows_kernel<NSTEP, R, WPB, false, true>), dim3(blocks), dim3(WPB * 64), 0, st, M, qv, scores, idx->n);
-      break;
-    }
-    case 5: {
-      constexpr int R = 1, WPB = 4;
-      int64_t tiles = (idx->n + R - 1) / R;
-      int blocks = (int)std::min<int64_t>((tiles + WPB - 1) / WPB, (int64_t)cus * 5);
-      hipLaunchKernelGGL((gemv_f32_rows_kernel<NSTEP, R, WPB, true, false>), dim3(blocks), dim3(WPB * 64), 0, st, M, qv, scores, idx->n);
-      break;
-    }
+    case 1: launch_persistent<NSTEP, 1, false>(idx, q, scores, st); return;
+    case 2: launch_persistent<NSTEP, 2, true>(idx, q, scores, st); return;
+    case 3: launch_oneshot<NSTEP, 2, 16, true>(idx, q, scores, st); return;
+    case 4: launch_oneshot<NSTEP, 1, 16, false>(idx, q, scores, st); return;
+    case 5: launch_oneshot<NSTEP, 1, 8, true>(idx, q, scores, st); return;
+    default: break;
   }
+  if constexpr (NSTEP <= 2) launch_oneshot<NSTEP, 4, 16, true>(idx, q, scores, st);
+  else if constexpr (NSTEP <= 4) launch_oneshot<NSTEP, 2, 16, true>(idx, q, scores, st);
+  else if constexpr (NSTEP <= 6) launch_oneshot<NSTEP, 1, 16, true>(idx, q, scores, st);
+  else launch_oneshot<NSTEP, 1, 8, true>(idx, q, scores, st);
 }
 
 template <int T>
