@@ -3,20 +3,29 @@
 //
 // Everything works on the unique 64-bit keys of keys.h, so "the k largest keys,
 // descending" IS the reference's output order (score desc, index desc) and does
-// not depend on scheduling.  Byte/integer work, HBM/L2-bound; no matrix cores.
+// not depend on scheduling.  Byte/integer work over the score vector (4 B per
+// corpus row, L2/MALL resident right after the score stage); no matrix cores.
 //
-// Path A (k <= SEL_KMAX): exact radix select of the k-th largest 32-bit score
-//   key in three histogram passes over the score vector (11 + 11 + 10 bits;
-//   4 MB per pass at 1M rows, L2/MALL resident right after the score stage),
-//   one filter pass that compacts the keys above the threshold (wave-aggregated
-//   appends) plus the ties AT the threshold, and a one-workgroup bitonic sort of
-//   the <= SORT_CAP survivors in LDS.  Each pass re-derives the previous
-//   passes' bucket choice from their histograms, so there are no tiny "pick"
-//   launches and no host round trips.
-// Path D (n <= SORT_CAP): the sort workgroup reads the scores directly.
-// Path B (any k): all n keys are sorted by a global bitonic network (LDS for
-//   strides < SORT_CAP, one launch per larger stride).  Used for k > SEL_KMAX,
-//   e.g. the reference's "rank the whole KB" call (n = 10,548).
+// Path A (k <= SEL_KMAX), three launches:
+//   1. window histogram: the top 16 bits of the orderable score key are a
+//      log-linear binning of the floats (128 bins per octave).  A 4096-bin
+//      window [2^-31, 2.0] (scores above 2 clamp into the top bin -- still
+//      monotone) is counted per workgroup in LDS and flushed to a global
+//      histogram.  One pass, no assumption on the score distribution beyond
+//      "the k best are positive"; otherwise step 3 falls back (exactly).
+//   2. filter: every workgroup suffix-scans the histogram for the bin holding
+//      the k-th best, then compacts the keys at or above that bin
+//      (wave-aggregated appends).  Typically k + a few dozen survivors.
+//   3. final, one workgroup: <= SORT_CAP survivors are sorted in LDS (bitonic);
+//      up to CAND_CAP go through an in-LDS 64-bit radix select first; if the
+//      window failed (fewer than k scores inside it, or a bin so crowded that
+//      the survivors overflow) the same radix select runs over the raw score
+//      vector -- slow (one CU), always exact, ties resolved by row bits.
+//      It then zeroes the histogram for the next search (no memset launch).
+// Path D (n <= SORT_CAP): the final workgroup reads the scores directly.
+// Path B (k > SEL_KMAX): all n keys are sorted by a global bitonic network (LDS
+//   for strides < SORT_CAP, one launch per larger stride), e.g. the reference's
+//   "rank the whole KB" call (n = 10,548).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -25,36 +34,45 @@
 
 namespace svs {
 
-constexpr int SEL_KMAX = 1024;    // path A handles k <= SEL_KMAX
+constexpr int SEL_KMAX = 2048;    // path A handles k <= SEL_KMAX
 constexpr int SORT_CAP = 4096;    // keys sorted in LDS by one workgroup (32 KiB)
-constexpr int TIE_CAP = SORT_CAP - SEL_KMAX;
-constexpr int HIST_BINS = 2048;   // 11 bits per pass
-constexpr int SEL_THREADS = 256;
+constexpr int CAND_CAP = 16384;   // survivors of the filter, per query
+constexpr int WBINS = 4096;       // window histogram bins
+constexpr uint32_t WTOP = 0xC000u;              // key16 of 2.0f
+constexpr uint32_t WBASE = WTOP - (WBINS - 1);  // key16 of ~2^-31
+constexpr int FA_THREADS = 512;   // histogram / filter workgroup
 constexpr int SORT_THREADS = 1024;
+constexpr int RS_BINS = 2048;     // in-LDS radix select: 11 bits per pass
+constexpr int PICK_MAX_PER = 8;
 
-// per-query scratch header, zeroed before the passes
-struct SelCounters {
-  uint32_t n_gt;   // keys strictly above the threshold appended so far
-  uint32_t n_eq;   // ties at the threshold seen (may exceed TIE_CAP)
+// per-query scratch: SelHeader followed by WBINS histogram words (all zero between searches)
+struct SelHeader {
+  uint32_t n_cand;  // keys appended by the filter (may exceed CAND_CAP: then invalid)
+  uint32_t flag;    // 0 ok, 1 fewer than k scores inside the window
   uint32_t pad0, pad1;
 };
+constexpr int SCR_WORDS = sizeof(SelHeader) / 4 + WBINS;
 
-__device__ __forceinline__ int pass_shift(int pass) { return pass == 0 ? 21 : (pass == 1 ? 10 : 0); }
-__device__ __forceinline__ int pass_bins(int pass) { return pass == 2 ? 1024 : 2048; }
+__device__ __forceinline__ int window_bin(uint32_t key32) {
+  const uint32_t k16 = key32 >> 16;
+  if (k16 < WBASE) return -1;
+  return (int)((k16 < WTOP ? k16 : WTOP) - WBASE);
+}
 
-// The first SEL_THREADS threads of a workgroup find, from a histogram of `bins`
-// buckets, the bucket holding the k_rem-th largest element counting from the
-// top.  Returns the bucket in *b_out and the rank inside it (1-based from the
-// bucket's top) in *k_out.  Every thread of the workgroup must call this (it
-// contains workgroup barriers); `sh` is SEL_THREADS+2 words of LDS.
-__device__ __forceinline__ void pick_bucket(const uint32_t* __restrict__ hist, int bins,
-                                            uint32_t k_rem, uint32_t* sh, uint32_t* b_out,
-                                            uint32_t* k_out) {
+// The first ACT threads of a workgroup find, from a histogram of `bins` buckets
+// (bins / ACT <= 8), the bucket holding the k_rem-th largest element counting
+// from the top.  *b_out = bucket (0xffffffff if the histogram holds fewer than
+// k_rem elements), *k_out = rank inside it (1-based from the bucket's top).
+// Every thread of the workgroup must call this (workgroup barriers inside);
+// `sh` is ACT+2 words of LDS.
+template <int ACT>
+__device__ __forceinline__ void pick_bucket(const uint32_t* hist, int bins, uint32_t k_rem,
+                                            uint32_t* sh, uint32_t* b_out, uint32_t* k_out) {
   const int tid = threadIdx.x;
-  const bool act = tid < SEL_THREADS;
-  const int per = bins / SEL_THREADS;  // 8 or 4
+  const bool act = tid < ACT;
+  const int per = bins / ACT;
   // thread t owns buckets [bins - (t+1)*per, bins - t*per): t = 0 is the top
-  uint32_t loc[8];
+  uint32_t loc[PICK_MAX_PER];
   uint32_t sum = 0;
   const int hi = bins - tid * per;
   if (act) {
@@ -64,9 +82,9 @@ __device__ __forceinline__ void pick_bucket(const uint32_t* __restrict__ hist, i
     }
     sh[tid] = sum;
   }
+  if (tid == 0) sh[ACT] = 0xffffffffu;
   __syncthreads();
-  // inclusive scan over SEL_THREADS partials (Hillis-Steele, 8 steps)
-  for (int off = 1; off < SEL_THREADS; off <<= 1) {
+  for (int off = 1; off < ACT; off <<= 1) {  // inclusive Hillis-Steele scan
     const uint32_t v = (act && tid >= off) ? sh[tid - off] : 0;
     __syncthreads();
     if (act) sh[tid] += v;
@@ -79,8 +97,8 @@ __device__ __forceinline__ void pick_bucket(const uint32_t* __restrict__ hist, i
       uint32_t c = excl;
       for (int i = 0; i < per; ++i) {
         if (c + loc[i] >= k_rem) {
-          sh[SEL_THREADS] = (uint32_t)(hi - 1 - i);
-          sh[SEL_THREADS + 1] = k_rem - c;
+          sh[ACT] = (uint32_t)(hi - 1 - i);
+          sh[ACT + 1] = k_rem - c;
           break;
         }
         c += loc[i];
@@ -88,102 +106,70 @@ __device__ __forceinline__ void pick_bucket(const uint32_t* __restrict__ hist, i
     }
   }
   __syncthreads();
-  *b_out = sh[SEL_THREADS];
-  *k_out = sh[SEL_THREADS + 1];
+  *b_out = sh[ACT];
+  *k_out = sh[ACT + 1];
   __syncthreads();
 }
 
-// Re-derive (prefix bits, remaining rank) after `npass` completed passes.
-__device__ __forceinline__ void derive_prefix(const uint32_t* __restrict__ hist_q, int npass,
-                                              uint32_t k, uint32_t* sh, uint32_t* prefix,
-                                              uint32_t* k_rem) {
-  uint32_t p = 0, kr = k;
-  for (int ps = 0; ps < npass; ++ps) {
-    uint32_t b, k2;
-    pick_bucket(hist_q + ps * HIST_BINS, pass_bins(ps), kr, sh, &b, &k2);
-    p |= b << pass_shift(ps);
-    kr = k2;
-  }
-  *prefix = p;
-  *k_rem = kr;
-}
-
-// grid = (blocks, nq).  hist is [nq][3][HIST_BINS], zeroed by the host before pass 0.
-__global__ __launch_bounds__(SEL_THREADS) void select_hist_kernel(
-    const float* __restrict__ scores, int64_t n, int64_t score_stride, uint32_t k, int pass,
-    uint32_t* __restrict__ hist) {
-  __shared__ uint32_t lh[HIST_BINS];
-  __shared__ uint32_t sh[SEL_THREADS + 2];
+// ---- path A, launch 1.  grid = (blocks, nq) ---------------------------------
+__global__ __launch_bounds__(FA_THREADS) void select_window_hist_kernel(
+    const float* __restrict__ scores, int64_t n, int64_t score_stride,
+    uint32_t* __restrict__ scratch) {
+  __shared__ uint32_t lh[WBINS];
   const int qi = blockIdx.y;
   const float* s = scores + (int64_t)qi * score_stride;
-  uint32_t* hq = hist + (int64_t)qi * 3 * HIST_BINS;
-  for (int i = threadIdx.x; i < HIST_BINS; i += SEL_THREADS) lh[i] = 0;
-  uint32_t prefix = 0, k_rem = k;
-  derive_prefix(hq, pass, k, sh, &prefix, &k_rem);  // ends with a barrier
-  const int shift = pass_shift(pass);
-  const uint32_t bmask = (uint32_t)pass_bins(pass) - 1;
-  // bits above this pass's field must equal the prefix
-  const uint32_t hmask = pass == 0 ? 0u : (pass == 1 ? 0xffe00000u : 0xfffffc00u);
-  const int64_t stride = (int64_t)gridDim.x * SEL_THREADS;
-  for (int64_t i = (int64_t)blockIdx.x * SEL_THREADS + threadIdx.x; i < n; i += stride) {
-    const uint32_t key = score_key(s[i]);
-    if ((key & hmask) == prefix) atomicAdd(&lh[(key >> shift) & bmask], 1u);
+  uint32_t* hist = scratch + (int64_t)qi * SCR_WORDS + sizeof(SelHeader) / 4;
+  for (int i = threadIdx.x; i < WBINS; i += FA_THREADS) lh[i] = 0;
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * FA_THREADS;
+  for (int64_t i = (int64_t)blockIdx.x * FA_THREADS + threadIdx.x; i < n; i += stride) {
+    const int b = window_bin(score_key(s[i]));
+    if (b >= 0) atomicAdd(&lh[b], 1u);
   }
   __syncthreads();
-  uint32_t* hp = hq + pass * HIST_BINS;
-  for (int i = threadIdx.x; i < HIST_BINS; i += SEL_THREADS) {
+  for (int i = threadIdx.x; i < WBINS; i += FA_THREADS) {
     const uint32_t c = lh[i];
-    if (c) atomicAdd(&hp[i], c);
+    if (c) atomicAdd(&hist[i], c);
   }
 }
 
-// grid = (blocks, nq).  cand is [nq][SORT_CAP] keys: [0, SEL_KMAX) strictly
-// greater than the threshold, [SEL_KMAX, SORT_CAP) ties at the threshold.
-__global__ __launch_bounds__(SEL_THREADS) void select_filter_kernel(
+// ---- path A, launch 2.  grid = (blocks, nq); cand is [nq][CAND_CAP] ----------
+__global__ __launch_bounds__(FA_THREADS) void select_window_filter_kernel(
     const float* __restrict__ scores, int64_t n, int64_t score_stride, uint32_t k,
-    const uint32_t* __restrict__ hist, uint64_t* __restrict__ cand,
-    SelCounters* __restrict__ counters) {
-  __shared__ uint32_t sh[SEL_THREADS + 2];
+    uint32_t* __restrict__ scratch, uint64_t* __restrict__ cand) {
+  __shared__ uint32_t sh[FA_THREADS + 2];
   const int qi = blockIdx.y;
   const float* s = scores + (int64_t)qi * score_stride;
-  uint32_t thr = 0, k_rem = k;
-  derive_prefix(hist + (int64_t)qi * 3 * HIST_BINS, 3, k, sh, &thr, &k_rem);
-  uint64_t* cq = cand + (int64_t)qi * SORT_CAP;
-  SelCounters* cn = counters + qi;
+  SelHeader* hdr = (SelHeader*)(scratch + (int64_t)qi * SCR_WORDS);
+  const uint32_t* hist = scratch + (int64_t)qi * SCR_WORDS + sizeof(SelHeader) / 4;
+  uint32_t bstar, krank;
+  pick_bucket<FA_THREADS>(hist, WBINS, k, sh, &bstar, &krank);
+  if (bstar == 0xffffffffu) {  // fewer than k scores inside the window: exact fallback in the final kernel
+    if (blockIdx.x == 0 && threadIdx.x == 0) hdr->flag = 1;
+    return;
+  }
+  uint64_t* cq = cand + (int64_t)qi * CAND_CAP;
   const int lane = threadIdx.x & 63;
-  const int64_t stride = (int64_t)gridDim.x * SEL_THREADS;
-  const int64_t start = (int64_t)blockIdx.x * SEL_THREADS + threadIdx.x;
-  // uniform trip count per wave so that ballots see whole waves
-  const int64_t iters = (n + stride - 1) / stride;
+  const int64_t stride = (int64_t)gridDim.x * FA_THREADS;
+  const int64_t start = (int64_t)blockIdx.x * FA_THREADS + threadIdx.x;
+  const int64_t iters = (n + stride - 1) / stride;  // uniform trip count: ballots see whole waves
   for (int64_t it = 0; it < iters; ++it) {
     const int64_t i = start + it * stride;
     uint32_t key = 0;
-    bool gt = false, eq = false;
+    bool keep = false;
     if (i < n) {
       key = score_key(s[i]);
-      gt = key > thr;
-      eq = key == thr;
+      keep = window_bin(key) >= (int)bstar;
     }
-    const unsigned long long mg = __ballot(gt);
-    const unsigned long long me = __ballot(eq);
-    if (mg) {
+    const unsigned long long m = __ballot(keep);
+    if (m) {
       uint32_t base = 0;
-      const int leader = __ffsll((long long)mg) - 1;
-      if (lane == leader) base = atomicAdd(&cn->n_gt, (uint32_t)__popcll(mg));
+      const int leader = __ffsll((long long)m) - 1;
+      if (lane == leader) base = atomicAdd(&hdr->n_cand, (uint32_t)__popcll(m));
       base = __shfl(base, leader, 64);
-      if (gt) {
-        const uint32_t slot = base + (uint32_t)__popcll(mg & ((1ull << lane) - 1));
-        if (slot < SEL_KMAX) cq[slot] = ((uint64_t)key << 32) | (uint32_t)i;
-      }
-    }
-    if (me) {
-      uint32_t base = 0;
-      const int leader = __ffsll((long long)me) - 1;
-      if (lane == leader) base = atomicAdd(&cn->n_eq, (uint32_t)__popcll(me));
-      base = __shfl(base, leader, 64);
-      if (eq) {
-        const uint32_t slot = base + (uint32_t)__popcll(me & ((1ull << lane) - 1));
-        if (slot < TIE_CAP) cq[SEL_KMAX + slot] = ((uint64_t)key << 32) | (uint32_t)i;
+      if (keep) {
+        const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+        if (slot < (uint32_t)CAND_CAP) cq[slot] = ((uint64_t)key << 32) | (uint32_t)i;
       }
     }
   }
@@ -229,63 +215,97 @@ __device__ __forceinline__ void emit_topk(const uint64_t* S, int count, int k, i
   }
 }
 
-// grid = nq, one workgroup per query.  mode 0: path A (candidates from the
-// filter); mode 1: path D (n <= SORT_CAP, read scores directly).
-__global__ __launch_bounds__(SORT_THREADS) void select_sort_kernel(
+// One workgroup: exact k-th largest of the M unique 64-bit keys key_at(0..M),
+// MSB-first radix select with an LDS histogram (11 bits per pass, early exit
+// as soon as a whole bucket is taken).  Returns T such that exactly k keys
+// satisfy key >= T.  lh: RS_BINS words, sh: 256+2 words of LDS.
+template <class KeyAt>
+__device__ __forceinline__ uint64_t block_radix_select(KeyAt key_at, int64_t M, uint32_t k,
+                                                       uint32_t* lh, uint32_t* sh) {
+  uint64_t prefix = 0, pmask = 0;
+  uint32_t k_rem = k;
+  for (int shift = 53; shift >= 0; shift -= 11) {   // 53,42,31,20,9 then the low 9 bits
+    for (int i = threadIdx.x; i < RS_BINS; i += blockDim.x) lh[i] = 0;
+    __syncthreads();
+    for (int64_t i = threadIdx.x; i < M; i += blockDim.x) {
+      const uint64_t key = key_at(i);
+      if ((key & pmask) == prefix) atomicAdd(&lh[(uint32_t)(key >> shift) & (RS_BINS - 1)], 1u);
+    }
+    __syncthreads();
+    uint32_t b, k2;
+    pick_bucket<256>(lh, RS_BINS, k_rem, sh, &b, &k2);
+    const uint32_t in_bucket = lh[b];
+    __syncthreads();
+    prefix |= (uint64_t)b << shift;
+    pmask |= (uint64_t)(RS_BINS - 1) << shift;
+    if (in_bucket == k2) return prefix;  // the whole bucket is selected
+    k_rem = k2;
+    if (shift == 9) {  // last pass: the remaining 9 low bits
+      for (int i = threadIdx.x; i < RS_BINS; i += blockDim.x) lh[i] = 0;
+      __syncthreads();
+      for (int64_t i = threadIdx.x; i < M; i += blockDim.x) {
+        const uint64_t key = key_at(i);
+        if ((key & pmask) == prefix) atomicAdd(&lh[(uint32_t)key & 511u], 1u);
+      }
+      __syncthreads();
+      pick_bucket<256>(lh, RS_BINS, k_rem, sh, &b, &k2);
+      return prefix | b;
+    }
+  }
+  return prefix;
+}
+
+// ---- path A launch 3 / path D.  grid = nq, one workgroup per query ------------
+// mode 0: path A (candidates from the filter); mode 1: path D (n <= SORT_CAP).
+__global__ __launch_bounds__(SORT_THREADS) void select_final_kernel(
     const float* __restrict__ scores, int64_t n, int64_t score_stride, int k_out, int count,
-    int mode, const uint32_t* __restrict__ hist, const uint64_t* __restrict__ cand,
-    const SelCounters* __restrict__ counters, int64_t row_offset, float* __restrict__ out_scores,
-    int64_t* __restrict__ out_rows) {
+    int mode, uint32_t* __restrict__ scratch, const uint64_t* __restrict__ cand,
+    int64_t row_offset, float* __restrict__ out_scores, int64_t* __restrict__ out_rows) {
   __shared__ uint64_t S[SORT_CAP];
-  __shared__ uint32_t sh[SEL_THREADS + 2];
+  __shared__ uint32_t lh[RS_BINS];
+  __shared__ uint32_t sh[256 + 2];
   __shared__ uint32_t s_cnt;
   const int qi = blockIdx.x;
   const float* s = scores + (int64_t)qi * score_stride;
   float* os = out_scores + (int64_t)qi * k_out;
   int64_t* orow = out_rows + (int64_t)qi * k_out;
-  int m = 0;
+  int m;
   if (mode == 1) {
     m = next_pow2((int)n < 2 ? 2 : (int)n);
     for (int i = threadIdx.x; i < m; i += blockDim.x) S[i] = i < n ? make_key(s[i], (uint32_t)i) : 0ull;
   } else {
-    const uint64_t* cq = cand + (int64_t)qi * SORT_CAP;
-    const uint32_t n_gt = counters[qi].n_gt;   // == count - (rank inside the tie bucket)
-    const uint32_t n_eq = counters[qi].n_eq;
-    if (n_eq <= (uint32_t)TIE_CAP) {
-      const int tot = (int)(n_gt + n_eq);
-      m = next_pow2(tot < 2 ? 2 : tot);
-      for (int i = threadIdx.x; i < m; i += blockDim.x) {
-        uint64_t v = 0ull;
-        if (i < (int)n_gt) v = cq[i];
-        else if (i < tot) v = cq[SEL_KMAX + (i - (int)n_gt)];
-        S[i] = v;
-      }
+    SelHeader* hdr = (SelHeader*)(scratch + (int64_t)qi * SCR_WORDS);
+    const uint64_t* cq = cand + (int64_t)qi * CAND_CAP;
+    const uint32_t flag = hdr->flag;
+    const uint32_t n_cand = hdr->n_cand;
+    if (flag == 0 && n_cand <= (uint32_t)SORT_CAP) {
+      m = next_pow2((int)n_cand < 2 ? 2 : (int)n_cand);
+      for (int i = threadIdx.x; i < m; i += blockDim.x) S[i] = i < (int)n_cand ? cq[i] : 0ull;
     } else {
-      // Slow path: more ties at the threshold than the candidate buffer holds
-      // (thousands of bit-identical scores).  The winners among ties are the
-      // LARGEST rows, so walk the score vector backwards in SORT_THREADS-row
-      // chunks collecting ties until enough are held.
-      uint32_t thr = 0, k_rem = (uint32_t)count;
-      derive_prefix(hist + (int64_t)qi * 3 * HIST_BINS, 3, (uint32_t)count, sh, &thr, &k_rem);
       if (threadIdx.x == 0) s_cnt = 0;
-      for (int i = threadIdx.x; i < SORT_CAP; i += blockDim.x) S[i] = i < (int)n_gt ? cq[i] : 0ull;
-      __syncthreads();
-      for (int64_t hi_row = n; hi_row > 0; hi_row -= SORT_THREADS) {
-        const int64_t i = hi_row - 1 - threadIdx.x;
-        if (i >= 0) {
-          const uint32_t key = score_key(s[i]);
-          if (key == thr) {
-            const uint32_t slot = atomicAdd(&s_cnt, 1u);
-            if (n_gt + slot < (uint32_t)SORT_CAP) S[n_gt + slot] = ((uint64_t)key << 32) | (uint32_t)i;
-          }
+      m = next_pow2(count < 2 ? 2 : count);
+      for (int i = threadIdx.x; i < m; i += blockDim.x) S[i] = 0ull;
+      if (flag == 0 && n_cand <= (uint32_t)CAND_CAP) {
+        auto key_at = [&](int64_t i) { return cq[i]; };
+        const uint64_t T = block_radix_select(key_at, (int64_t)n_cand, (uint32_t)count, lh, sh);
+        for (int64_t i = threadIdx.x; i < (int64_t)n_cand; i += blockDim.x) {
+          const uint64_t key = cq[i];
+          if (key >= T) S[atomicAdd(&s_cnt, 1u)] = key;
         }
-        __syncthreads();
-        const uint32_t have = s_cnt;
-        __syncthreads();
-        if (have >= k_rem) break;  // every tie with a row above hi_row - chunk is held
+      } else {  // exact fallback over the raw scores (one CU; rare)
+        auto key_at = [&](int64_t i) { return make_key(s[i], (uint32_t)i); };
+        const uint64_t T = block_radix_select(key_at, n, (uint32_t)count, lh, sh);
+        for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+          const uint64_t key = make_key(s[i], (uint32_t)i);
+          if (key >= T) S[atomicAdd(&s_cnt, 1u)] = key;
+        }
       }
-      m = SORT_CAP;
     }
+    // leave the scratch zeroed for the next search on this context (after every
+    // thread has read the header)
+    __syncthreads();
+    uint32_t* w = scratch + (int64_t)qi * SCR_WORDS;
+    for (int i = threadIdx.x; i < SCR_WORDS; i += blockDim.x) w[i] = 0;
   }
   __syncthreads();
   bitonic_sort_lds_desc(S, m);

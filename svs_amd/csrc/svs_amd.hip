@@ -280,29 +280,26 @@ int enqueue_search(svs_index* idx, Ctx* c, const float* q_dev, int nq, int k, in
 
   if (k > 0) {
     if (n <= SORT_CAP) {
-      hipLaunchKernelGGL(select_sort_kernel, dim3(nq), dim3(SORT_THREADS), 0, st, c->scores, n, n, k,
-                         count, 1, (const uint32_t*)nullptr, (const uint64_t*)nullptr,
-                         (const SelCounters*)nullptr, idx->row_offset, out_s, out_r);
+      hipLaunchKernelGGL(select_final_kernel, dim3(nq), dim3(SORT_THREADS), 0, st, c->scores, n, n, k,
+                         count, 1, (uint32_t*)nullptr, (const uint64_t*)nullptr, idx->row_offset, out_s, out_r);
     } else if (count <= SEL_KMAX) {
       if ((size_t)nq > c->hist_cap) {
         if (c->hist) HIP_TRY(hipFree(c->hist));
         if (c->cand) HIP_TRY(hipFree(c->cand));
         c->hist = nullptr; c->cand = nullptr; c->hist_cap = 0;
-        // hist and counters are contiguous so that one memset clears both
-        HIP_TRY(hipMalloc((void**)&c->hist, (size_t)nq * (3 * HIST_BINS * sizeof(uint32_t) + sizeof(SelCounters))));
-        HIP_TRY(hipMalloc((void**)&c->cand, (size_t)nq * SORT_CAP * sizeof(uint64_t)));
+        const size_t scr_bytes = (size_t)nq * SCR_WORDS * sizeof(uint32_t);
+        HIP_TRY(hipMalloc((void**)&c->hist, scr_bytes));
+        HIP_TRY(hipMalloc((void**)&c->cand, (size_t)nq * CAND_CAP * sizeof(uint64_t)));
+        // zeroed once; select_final_kernel leaves it zeroed after every search
+        HIP_TRY(hipMemsetAsync(c->hist, 0, scr_bytes, st));
         c->hist_cap = nq;
       }
-      SelCounters* counters = (SelCounters*)(c->hist + (size_t)nq * 3 * HIST_BINS);
-      HIP_TRY(hipMemsetAsync(c->hist, 0, (size_t)nq * (3 * HIST_BINS * sizeof(uint32_t) + sizeof(SelCounters)), st));
-      int blocks = (int)std::min<int64_t>(std::max<int64_t>(n / 4096, 1), 512);
-      for (int pass = 0; pass < 3; ++pass)
-        hipLaunchKernelGGL(select_hist_kernel, dim3(blocks, nq), dim3(SEL_THREADS), 0, st, c->scores, n, n,
-                           (uint32_t)count, pass, c->hist);
-      hipLaunchKernelGGL(select_filter_kernel, dim3(blocks, nq), dim3(SEL_THREADS), 0, st, c->scores, n, n,
-                         (uint32_t)count, c->hist, c->cand, counters);
-      hipLaunchKernelGGL(select_sort_kernel, dim3(nq), dim3(SORT_THREADS), 0, st, c->scores, n, n, k, count, 0,
-                         c->hist, c->cand, counters, idx->row_offset, out_s, out_r);
+      const int blocks = (int)std::min<int64_t>(std::max<int64_t>(n / 8192, 1), 1024);
+      hipLaunchKernelGGL(select_window_hist_kernel, dim3(blocks, nq), dim3(FA_THREADS), 0, st, c->scores, n, n, c->hist);
+      hipLaunchKernelGGL(select_window_filter_kernel, dim3(blocks, nq), dim3(FA_THREADS), 0, st, c->scores, n, n,
+                         (uint32_t)count, c->hist, c->cand);
+      hipLaunchKernelGGL(select_final_kernel, dim3(nq), dim3(SORT_THREADS), 0, st, c->scores, n, n, k, count, 0,
+                         c->hist, c->cand, idx->row_offset, out_s, out_r);
     } else {
       int64_t npad;
       next_pow2_i64(n, &npad);
