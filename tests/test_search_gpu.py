@@ -218,3 +218,26 @@ def test_concurrent_searches_and_release(gpu):
     for t in ts:
         t.join()
     assert not errors, errors
+
+
+def test_select_window_fallbacks(gpu):
+    """The fast top-k path counts scores in a log-binned window [2^-31, 2]; outside
+    it (negative / zero / huge scores, crowded bins) an exact in-kernel fallback
+    takes over.  Every branch must agree with the rule-based oracle."""
+    q = np.array([1.0], dtype=np.float32)
+    rng = np.random.default_rng(8)
+    cases = {
+        "all negative": -np.abs(rng.standard_normal(30000).astype(np.float32)) - 0.01,
+        "only 40 positive": np.concatenate([-np.abs(rng.standard_normal(29960)), np.abs(rng.standard_normal(40))]).astype(np.float32),
+        "zeros and negatives": np.concatenate([np.zeros(5000), -np.abs(rng.standard_normal(20000))]).astype(np.float32),
+        "scores above 2 (unnormalised)": (rng.standard_normal(30000) * 50).astype(np.float32),
+        "crowded octave": (0.75 + rng.random(200000) * 1e-3).astype(np.float32),
+        "tiny positives": (rng.random(30000) * 1e-12).astype(np.float32),
+        "infinities": np.concatenate([rng.standard_normal(9000), [np.inf, -np.inf, np.inf]]).astype(np.float32),
+    }
+    for name, v in cases.items():
+        v = rng.permutation(v)
+        idx = _index(v[:, None])
+        for k in (1, 100, 1000, 2048):
+            assert idx.search(q, k) == oracle.total_order_top_k(v, k), (name, k)
+        idx.release()
