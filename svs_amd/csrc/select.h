@@ -31,12 +31,13 @@
 #include <stdint.h>
 
 #include "keys.h"
+#include "topk_state.h"
 
 namespace svs {
 
 constexpr int SEL_KMAX = 2048;    // path A handles k <= SEL_KMAX
 constexpr int SORT_CAP = 4096;    // keys sorted in LDS by one workgroup (32 KiB)
-constexpr int CAND_CAP = 16384;   // survivors of the filter, per query
+constexpr int CAND_CAP = 32768;   // candidate keys per query (fused pre-filter or window filter)
 constexpr int WBINS = 4096;       // window histogram bins
 constexpr uint32_t WTOP = 0xC000u;              // key16 of 2.0f
 constexpr uint32_t WBASE = WTOP - (WBINS - 1);  // key16 of ~2^-31
@@ -256,7 +257,8 @@ __device__ __forceinline__ uint64_t block_radix_select(KeyAt key_at, int64_t M, 
 }
 
 // ---- path A launch 3 / path D.  grid = nq, one workgroup per query ------------
-// mode 0: path A (candidates from the filter); mode 1: path D (n <= SORT_CAP).
+// mode 0: path A, candidates from the window filter; mode 1: path D (n <= SORT_CAP);
+// mode 2: path A, candidates from the pre-filter fused into the score kernel.
 __global__ __launch_bounds__(SORT_THREADS) void select_final_kernel(
     const float* __restrict__ scores, int64_t n, int64_t score_stride, int k_out, int count,
     int mode, uint32_t* __restrict__ scratch, const uint64_t* __restrict__ cand,
@@ -274,10 +276,18 @@ __global__ __launch_bounds__(SORT_THREADS) void select_final_kernel(
     m = next_pow2((int)n < 2 ? 2 : (int)n);
     for (int i = threadIdx.x; i < m; i += blockDim.x) S[i] = i < n ? make_key(s[i], (uint32_t)i) : 0ull;
   } else {
-    SelHeader* hdr = (SelHeader*)(scratch + (int64_t)qi * SCR_WORDS);
+    const int scr_words = mode == 2 ? SEL_STATE_WORDS : SCR_WORDS;
     const uint64_t* cq = cand + (int64_t)qi * CAND_CAP;
-    const uint32_t flag = hdr->flag;
-    const uint32_t n_cand = hdr->n_cand;
+    uint32_t flag, n_cand;
+    if (mode == 2) {
+      const SelState* st = (const SelState*)(scratch + (int64_t)qi * SEL_STATE_WORDS);
+      flag = 0;
+      n_cand = st->n_cand;
+    } else {
+      const SelHeader* hdr = (const SelHeader*)(scratch + (int64_t)qi * SCR_WORDS);
+      flag = hdr->flag;
+      n_cand = hdr->n_cand;
+    }
     if (flag == 0 && n_cand <= (uint32_t)SORT_CAP) {
       m = next_pow2((int)n_cand < 2 ? 2 : (int)n_cand);
       for (int i = threadIdx.x; i < m; i += blockDim.x) S[i] = i < (int)n_cand ? cq[i] : 0ull;
@@ -304,8 +314,8 @@ __global__ __launch_bounds__(SORT_THREADS) void select_final_kernel(
     // leave the scratch zeroed for the next search on this context (after every
     // thread has read the header)
     __syncthreads();
-    uint32_t* w = scratch + (int64_t)qi * SCR_WORDS;
-    for (int i = threadIdx.x; i < SCR_WORDS; i += blockDim.x) w[i] = 0;
+    uint32_t* w = scratch + (int64_t)qi * scr_words;
+    for (int i = threadIdx.x; i < scr_words; i += blockDim.x) w[i] = 0;
   }
   __syncthreads();
   bitonic_sort_lds_desc(S, m);

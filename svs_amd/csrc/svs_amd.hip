@@ -58,7 +58,10 @@ struct Ctx {
   float* out_s = nullptr;       int64_t* out_r = nullptr; size_t out_cap = 0;  // entries
   float* q_pin = nullptr;       size_t q_pin_cap = 0;
   float* out_s_pin = nullptr;   int64_t* out_r_pin = nullptr; size_t out_pin_cap = 0;
-  hipEvent_t busy = nullptr;    bool busy_valid = false;
+  // Scratch is reused in stream order.  A context stays with the stream that
+  // last used it; handing it to ANOTHER stream first drains the old one.
+  hipStream_t last_stream = nullptr;
+  bool async_pending = false;
 };
 
 }  // namespace
@@ -77,7 +80,7 @@ struct svs_index {
   std::condition_variable cv;
   std::vector<Ctx*> free_ctx;
   int n_ctx = 0;
-  static constexpr int kMaxCtx = 4;
+  static constexpr int kMaxCtx = 8;
 
   std::atomic<int> timing{0};
   std::atomic<int> variant{0};
@@ -88,7 +91,7 @@ namespace {
 
 void ctx_destroy(Ctx* c) {
   if (!c) return;
-  if (c->busy_valid) (void)hipEventSynchronize(c->busy);
+  if (c->async_pending) (void)hipStreamSynchronize(c->last_stream);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   (void)hipFree(c->q_dev);
   (void)hipFree(c->scores);
@@ -100,7 +103,6 @@ void ctx_destroy(Ctx* c) {
   (void)hipHostFree(c->q_pin);
   (void)hipHostFree(c->out_s_pin);
   (void)hipHostFree(c->out_r_pin);
-  if (c->busy) (void)hipEventDestroy(c->busy);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -117,31 +119,50 @@ void index_destroy(svs_index* idx) {
   delete idx;
 }
 
-int ctx_acquire(svs_index* idx, Ctx** out) {
-  std::unique_lock<std::mutex> lk(idx->mu);
-  for (;;) {
-    if (!idx->free_ctx.empty()) {
-      *out = idx->free_ctx.back();
-      idx->free_ctx.pop_back();
-      return SVS_OK;
-    }
-    if (idx->n_ctx < svs_index::kMaxCtx) {
-      idx->n_ctx++;
-      lk.unlock();
-      Ctx* c = new (std::nothrow) Ctx();
-      hipError_t e = c ? hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) : hipErrorOutOfMemory;
-      if (e == hipSuccess) e = hipEventCreateWithFlags(&c->busy, hipEventDisableTiming);
-      if (e != hipSuccess) {
-        ctx_destroy(c);
-        lk.lock();
-        idx->n_ctx--;
-        return fail(SVS_ERR_DEVICE, "search context: %s", hipGetErrorString(e));
+// `want`: the stream the caller will enqueue on (nullptr = the context's own).
+int ctx_acquire(svs_index* idx, hipStream_t want, bool own_stream, Ctx** out) {
+  Ctx* c = nullptr;
+  {
+    std::unique_lock<std::mutex> lk(idx->mu);
+    for (;;) {
+      int pick = -1;
+      for (int i = (int)idx->free_ctx.size() - 1; i >= 0; --i) {
+        Ctx* f = idx->free_ctx[i];
+        if (own_stream ? !f->async_pending : (f->async_pending && f->last_stream == want)) {
+          pick = i;
+          break;
+        }
       }
-      *out = c;
-      return SVS_OK;
+      if (pick < 0 && idx->n_ctx < svs_index::kMaxCtx) {
+        idx->n_ctx++;
+        lk.unlock();
+        c = new (std::nothrow) Ctx();
+        hipError_t e = c ? hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) : hipErrorOutOfMemory;
+        if (e != hipSuccess) {
+          ctx_destroy(c);
+          lk.lock();
+          idx->n_ctx--;
+          return fail(SVS_ERR_DEVICE, "search context: %s", hipGetErrorString(e));
+        }
+        *out = c;
+        return SVS_OK;
+      }
+      if (pick < 0 && !idx->free_ctx.empty()) pick = (int)idx->free_ctx.size() - 1;
+      if (pick >= 0) {
+        c = idx->free_ctx[pick];
+        idx->free_ctx.erase(idx->free_ctx.begin() + pick);
+        break;
+      }
+      idx->cv.wait(lk);
     }
-    idx->cv.wait(lk);
   }
+  // migrating between streams: drain the previous user of this scratch (rare)
+  if (c->async_pending && (own_stream || c->last_stream != want)) {
+    (void)hipStreamSynchronize(c->last_stream);  // a destroyed stream has already drained
+    c->async_pending = false;
+  }
+  *out = c;
+  return SVS_OK;
 }
 
 void ctx_release(svs_index* idx, Ctx* c) {
@@ -185,11 +206,11 @@ int next_pow2_i64(int64_t v, int64_t* out) {
 
 // ---- score stage launch -----------------------------------------------------
 template <int NSTEP, int R, int WPB, bool NT>
-void launch_oneshot(const svs_index* idx, const float* q, float* scores, hipStream_t st) {
+void launch_oneshot(const svs_index* idx, const float* q, float* scores, hipStream_t st, FuseArgs fa) {
   const int64_t rows_per_block = (int64_t)R * WPB;
   const int64_t blocks = (idx->n + rows_per_block - 1) / rows_per_block;
   hipLaunchKernelGGL((gemv_f32_oneshot_kernel<NSTEP, R, WPB, NT, false>), dim3((unsigned)blocks), dim3(WPB * 64), 0, st,
-                     (const v4f*)idx->rows, (const v4f*)q, scores, idx->n);
+                     (const v4f*)idx->rows, (const v4f*)q, scores, idx->n, fa);
 }
 
 template <int NSTEP, int R, bool NT>
@@ -204,20 +225,22 @@ void launch_persistent(const svs_index* idx, const float* q, float* scores, hipS
 // Default geometry per row length (measured at NSTEP = 6: one-shot, 16-wave
 // workgroups, one row per wave, nontemporal loads: 7.2 TB/s on MI355X).
 // Short rows take several rows per wave so a wave still has >= 4 KiB in flight.
+// Returns true when the kernel honoured `fa` (the fused top-k pre-filter).
 template <int NSTEP>
-void launch_rows(const svs_index* idx, const float* q, float* scores, hipStream_t st, int variant) {
+bool launch_rows(const svs_index* idx, const float* q, float* scores, hipStream_t st, int variant, FuseArgs fa) {
   switch (variant) {
-    case 1: launch_persistent<NSTEP, 1, false>(idx, q, scores, st); return;
-    case 2: launch_persistent<NSTEP, 2, true>(idx, q, scores, st); return;
-    case 3: launch_oneshot<NSTEP, 2, 16, true>(idx, q, scores, st); return;
-    case 4: launch_oneshot<NSTEP, 1, 16, false>(idx, q, scores, st); return;
-    case 5: launch_oneshot<NSTEP, 1, 8, true>(idx, q, scores, st); return;
+    case 1: launch_persistent<NSTEP, 1, false>(idx, q, scores, st); return false;
+    case 2: launch_persistent<NSTEP, 2, true>(idx, q, scores, st); return false;
+    case 3: launch_oneshot<NSTEP, 2, 16, true>(idx, q, scores, st, fa); return true;
+    case 4: launch_oneshot<NSTEP, 1, 16, false>(idx, q, scores, st, fa); return true;
+    case 5: launch_oneshot<NSTEP, 1, 8, true>(idx, q, scores, st, fa); return true;
     default: break;
   }
-  if constexpr (NSTEP <= 2) launch_oneshot<NSTEP, 4, 16, true>(idx, q, scores, st);
-  else if constexpr (NSTEP <= 4) launch_oneshot<NSTEP, 2, 16, true>(idx, q, scores, st);
-  else if constexpr (NSTEP <= 6) launch_oneshot<NSTEP, 1, 16, true>(idx, q, scores, st);
-  else launch_oneshot<NSTEP, 1, 8, true>(idx, q, scores, st);
+  if constexpr (NSTEP <= 2) launch_oneshot<NSTEP, 4, 16, true>(idx, q, scores, st, fa);
+  else if constexpr (NSTEP <= 4) launch_oneshot<NSTEP, 2, 16, true>(idx, q, scores, st, fa);
+  else if constexpr (NSTEP <= 6) launch_oneshot<NSTEP, 1, 16, true>(idx, q, scores, st, fa);
+  else launch_oneshot<NSTEP, 1, 8, true>(idx, q, scores, st, fa);
+  return true;
 }
 
 template <int T>
@@ -229,20 +252,23 @@ void launch_generic(const svs_index* idx, const float* q, float* scores, hipStre
                      (const v4f*)idx->rows, q, scores, idx->n, idx->d, idx->ld / 4);
 }
 
-// q: device, d floats (unpadded); scores: device, n floats
-int launch_scores(const svs_index* idx, const float* q, float* scores, hipStream_t st) {
+// q: device, d floats (unpadded); scores: device, n floats.  *fused tells the
+// caller whether the candidate list of `fa` was produced.
+int launch_scores(const svs_index* idx, const float* q, float* scores, hipStream_t st, FuseArgs fa, bool* fused) {
+  *fused = false;
   if (idx->dtype != SVS_DTYPE_F32) return fail(SVS_ERR_UNSUPPORTED, "dtype %d not implemented yet", idx->dtype);
   const int variant = idx->variant.load();
+  if (variant == 6) fa.state = nullptr;  // A/B: unfused top-k
   const bool q_aligned = (((uintptr_t)q) & 15) == 0;
   if (idx->ld == idx->d && idx->ld % 256 == 0 && q_aligned) {
     switch (idx->ld / 256) {
-      case 1: launch_rows<1>(idx, q, scores, st, variant); return SVS_OK;
-      case 2: launch_rows<2>(idx, q, scores, st, variant); return SVS_OK;
-      case 3: launch_rows<3>(idx, q, scores, st, variant); return SVS_OK;
-      case 4: launch_rows<4>(idx, q, scores, st, variant); return SVS_OK;
-      case 6: launch_rows<6>(idx, q, scores, st, variant); return SVS_OK;
-      case 8: launch_rows<8>(idx, q, scores, st, variant); return SVS_OK;
-      case 12: launch_rows<12>(idx, q, scores, st, variant); return SVS_OK;
+      case 1: *fused = launch_rows<1>(idx, q, scores, st, variant, fa) && fa.state; return SVS_OK;
+      case 2: *fused = launch_rows<2>(idx, q, scores, st, variant, fa) && fa.state; return SVS_OK;
+      case 3: *fused = launch_rows<3>(idx, q, scores, st, variant, fa) && fa.state; return SVS_OK;
+      case 4: *fused = launch_rows<4>(idx, q, scores, st, variant, fa) && fa.state; return SVS_OK;
+      case 6: *fused = launch_rows<6>(idx, q, scores, st, variant, fa) && fa.state; return SVS_OK;
+      case 8: *fused = launch_rows<8>(idx, q, scores, st, variant, fa) && fa.state; return SVS_OK;
+      case 12: *fused = launch_rows<12>(idx, q, scores, st, variant, fa) && fa.state; return SVS_OK;
       default: break;
     }
   }
@@ -263,6 +289,19 @@ int enqueue_search(svs_index* idx, Ctx* c, const float* q_dev, int nq, int k, in
   const int64_t n = idx->n;
   int rc;
   if ((rc = grow_dev(&c->scores, &c->scores_cap, (size_t)nq * (size_t)n)) != SVS_OK) return rc;
+  const bool path_a = k > 0 && n > SORT_CAP && count <= SEL_KMAX;
+  static_assert(SEL_STATE_WORDS == SCR_WORDS, "both top-k scratch layouts share one allocation");
+  if (path_a && (size_t)nq > c->hist_cap) {
+    if (c->hist) HIP_TRY(hipFree(c->hist));
+    if (c->cand) HIP_TRY(hipFree(c->cand));
+    c->hist = nullptr; c->cand = nullptr; c->hist_cap = 0;
+    const size_t scr_bytes = (size_t)nq * SCR_WORDS * sizeof(uint32_t);
+    HIP_TRY(hipMalloc((void**)&c->hist, scr_bytes));
+    HIP_TRY(hipMalloc((void**)&c->cand, (size_t)nq * CAND_CAP * sizeof(uint64_t)));
+    // zeroed once; select_final_kernel leaves it zeroed after every search
+    HIP_TRY(hipMemsetAsync(c->hist, 0, scr_bytes, st));
+    c->hist_cap = nq;
+  }
 
   EvTriple ev{};
   const bool timed = idx->timing.load() != 0;
@@ -272,9 +311,15 @@ int enqueue_search(svs_index* idx, Ctx* c, const float* q_dev, int nq, int k, in
     HIP_TRY(hipEventCreate(&ev.e2));
     HIP_TRY(hipEventRecord(ev.e0, st));
   }
+  bool fused_all = true;
   for (int qi = 0; qi < nq; ++qi) {
-    rc = launch_scores(idx, q_dev + (size_t)qi * idx->d, c->scores + (size_t)qi * n, st);
+    FuseArgs fa{nullptr, nullptr, 0, 0};
+    if (path_a) fa = FuseArgs{(SelState*)(c->hist + (size_t)qi * SEL_STATE_WORDS), c->cand + (size_t)qi * CAND_CAP,
+                              (uint32_t)count, (uint32_t)CAND_CAP};
+    bool fused = false;
+    rc = launch_scores(idx, q_dev + (size_t)qi * idx->d, c->scores + (size_t)qi * n, st, fa, &fused);
     if (rc != SVS_OK) return rc;
+    fused_all = fused_all && fused;
   }
   if (timed) HIP_TRY(hipEventRecord(ev.e1, st));
 
@@ -282,18 +327,10 @@ int enqueue_search(svs_index* idx, Ctx* c, const float* q_dev, int nq, int k, in
     if (n <= SORT_CAP) {
       hipLaunchKernelGGL(select_final_kernel, dim3(nq), dim3(SORT_THREADS), 0, st, c->scores, n, n, k,
                          count, 1, (uint32_t*)nullptr, (const uint64_t*)nullptr, idx->row_offset, out_s, out_r);
-    } else if (count <= SEL_KMAX) {
-      if ((size_t)nq > c->hist_cap) {
-        if (c->hist) HIP_TRY(hipFree(c->hist));
-        if (c->cand) HIP_TRY(hipFree(c->cand));
-        c->hist = nullptr; c->cand = nullptr; c->hist_cap = 0;
-        const size_t scr_bytes = (size_t)nq * SCR_WORDS * sizeof(uint32_t);
-        HIP_TRY(hipMalloc((void**)&c->hist, scr_bytes));
-        HIP_TRY(hipMalloc((void**)&c->cand, (size_t)nq * CAND_CAP * sizeof(uint64_t)));
-        // zeroed once; select_final_kernel leaves it zeroed after every search
-        HIP_TRY(hipMemsetAsync(c->hist, 0, scr_bytes, st));
-        c->hist_cap = nq;
-      }
+    } else if (path_a && fused_all) {
+      hipLaunchKernelGGL(select_final_kernel, dim3(nq), dim3(SORT_THREADS), 0, st, c->scores, n, n, k, count, 2,
+                         c->hist, c->cand, idx->row_offset, out_s, out_r);
+    } else if (path_a) {
       const int blocks = (int)std::min<int64_t>(std::max<int64_t>(n / 8192, 1), 1024);
       hipLaunchKernelGGL(select_window_hist_kernel, dim3(blocks, nq), dim3(FA_THREADS), 0, st, c->scores, n, n, c->hist);
       hipLaunchKernelGGL(select_window_filter_kernel, dim3(blocks, nq), dim3(FA_THREADS), 0, st, c->scores, n, n,
@@ -498,12 +535,8 @@ int32_t svs_index_search(svs_index* idx, const float* queries, int32_t nq, int32
   struct Guard { svs_index* i; ~Guard() { svs_index_release(i); } } guard{idx};
   HIP_TRY(hipSetDevice(idx->device));
   Ctx* c = nullptr;
-  if ((rc = ctx_acquire(idx, &c)) != SVS_OK) return rc;
+  if ((rc = ctx_acquire(idx, nullptr, true, &c)) != SVS_OK) return rc;
   struct CtxGuard { svs_index* i; Ctx* c; ~CtxGuard() { ctx_release(i, c); } } cg{idx, c};
-  if (c->busy_valid) {
-    HIP_TRY(hipEventSynchronize(c->busy));
-    c->busy_valid = false;
-  }
   const size_t qn = (size_t)nq * (size_t)d, on = (size_t)nq * (size_t)count;
   if ((rc = grow_dev(&c->q_dev, &c->q_cap, qn)) != SVS_OK) return rc;
   if ((rc = grow_out(c, on)) != SVS_OK) return rc;
@@ -552,15 +585,14 @@ int32_t svs_index_search_device(svs_index* idx, const float* dev_queries, int32_
   HIP_TRY(hipSetDevice(idx->device));
   hipStream_t st = (hipStream_t)hip_stream;
   Ctx* c = nullptr;
-  if ((rc = ctx_acquire(idx, &c)) != SVS_OK) return rc;
+  if ((rc = ctx_acquire(idx, st, false, &c)) != SVS_OK) return rc;
   struct CtxGuard { svs_index* i; Ctx* c; ~CtxGuard() { ctx_release(i, c); } } cg{idx, c};
-  // scratch of this context may still be in use by an earlier enqueue on another stream
-  if (c->busy_valid) HIP_TRY(hipStreamWaitEvent(st, c->busy, 0));
+  // growing scratch frees buffers that earlier work on this stream may still read
   const size_t need_scores = (size_t)nq * (size_t)idx->n;
-  if (need_scores > c->scores_cap && c->busy_valid) HIP_TRY(hipEventSynchronize(c->busy));
+  if (c->async_pending && (need_scores > c->scores_cap || (size_t)nq > c->hist_cap)) HIP_TRY(hipStreamSynchronize(st));
   rc = enqueue_search(idx, c, dev_queries, nq, k, count, dev_out_scores, dev_out_rows, st);
-  HIP_TRY(hipEventRecord(c->busy, st));
-  c->busy_valid = true;
+  c->last_stream = st;
+  c->async_pending = true;
   return rc;
 }
 
@@ -572,16 +604,13 @@ int32_t svs_index_scores(svs_index* idx, const float* query, int32_t d, float* o
   struct Guard { svs_index* i; ~Guard() { svs_index_release(i); } } guard{idx};
   HIP_TRY(hipSetDevice(idx->device));
   Ctx* c = nullptr;
-  if ((rc = ctx_acquire(idx, &c)) != SVS_OK) return rc;
+  if ((rc = ctx_acquire(idx, nullptr, true, &c)) != SVS_OK) return rc;
   struct CtxGuard { svs_index* i; Ctx* c; ~CtxGuard() { ctx_release(i, c); } } cg{idx, c};
-  if (c->busy_valid) {
-    HIP_TRY(hipEventSynchronize(c->busy));
-    c->busy_valid = false;
-  }
   if ((rc = grow_dev(&c->q_dev, &c->q_cap, (size_t)d)) != SVS_OK) return rc;
   if ((rc = grow_dev(&c->scores, &c->scores_cap, (size_t)idx->n)) != SVS_OK) return rc;
   HIP_TRY(hipMemcpyAsync(c->q_dev, query, (size_t)d * sizeof(float), hipMemcpyHostToDevice, c->stream));
-  if ((rc = launch_scores(idx, c->q_dev, c->scores, c->stream)) != SVS_OK) return rc;
+  bool fused = false;
+  if ((rc = launch_scores(idx, c->q_dev, c->scores, c->stream, FuseArgs{nullptr, nullptr, 0, 0}, &fused)) != SVS_OK) return rc;
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(out_scores, c->scores, (size_t)idx->n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -627,7 +656,7 @@ int32_t svs_index_get_timing(svs_index* idx, svs_timing_t* out) {
 
 int32_t svs_index_set_variant(svs_index* idx, int32_t variant) {
   if (!idx) return fail(SVS_ERR_INVALID, "null index");
-  if (variant < 0 || variant > 5) return fail(SVS_ERR_INVALID, "unknown variant %d", variant);
+  if (variant < 0 || variant > 6) return fail(SVS_ERR_INVALID, "unknown variant %d", variant);
   idx->variant.store(variant);
   return SVS_OK;
 }
