@@ -65,6 +65,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=20)
     ap.add_argument("--latency-iters", type=int, default=200)
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="searches kept in flight on separate HIP streams (2 lets the top-k "
+                         "stage of query i overlap the score stage of query i+1)")
     args = ap.parse_args()
 
     import torch
@@ -114,14 +117,17 @@ def main():
     rec = s_bytes + k * 8
     local = torch.zeros((K + W, rec), device=dev, dtype=torch.uint8)
     gathered = torch.zeros((K + W, world, rec), device=dev, dtype=torch.uint8) if world > 1 else None
-    stream = torch.cuda.current_stream().cuda_stream
+    streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.inflight))]
     count = min(k, n_local)
+    torch.cuda.synchronize()
 
     def step(i):
+        st = streams[i % len(streams)]
         base = local[i].data_ptr()
-        idx.search_device(queries[i].data_ptr(), 1, d, k, base, base + s_bytes, stream)
+        idx.search_device(queries[i].data_ptr(), 1, d, k, base, base + s_bytes, st.cuda_stream)
         if world > 1:
-            return dist.all_gather_into_tensor(gathered[i].view(-1), local[i], async_op=True)
+            with torch.cuda.stream(st):
+                return dist.all_gather_into_tensor(gathered[i].view(-1), local[i], async_op=True)
         return None
 
     def finish(works, i0, i1):
@@ -200,7 +206,7 @@ def main():
                             "HBM-resident GEMV + top-k%s" % (n_total, d, k, "" if world == 1 else ", row-sharded over %d GPUs + RCCL all-gather + host merge" % world),
                 "rows_per_gpu": n_local, "dim": d, "k": k, "queries_per_step": 1,
                 "corpus": "unit-norm gaussian, seed %d, generated on device" % args.seed,
-                "variant": args.variant,
+                "variant": args.variant, "searches_in_flight": len(streams),
             },
             "p50_latency_ms": lat_ms,
             "stage_ms": {"score": kernel_ms, "select": select_ms / max(launches, 1)},

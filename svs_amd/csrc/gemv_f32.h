@@ -22,8 +22,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "topk_state.h"
-
 namespace svs {
 
 // native clang vector (HIP's v4f class is not accepted by the nontemporal builtin)
@@ -157,14 +155,12 @@ __global__ __launch_bounds__(WPB * 64) void gemv_f32_rows_kernel(
 template <int NSTEP, int R, int WPB, bool NT, bool QLDS>
 __global__ __launch_bounds__(WPB * 64) void gemv_f32_oneshot_kernel(
     const v4f* __restrict__ M, const v4f* __restrict__ q, float* __restrict__ scores,
-    int64_t n, FuseArgs fa) {
+    int64_t n) {
   constexpr int LD4 = NSTEP * 64;
   __shared__ v4f qs[QLDS ? LD4 : 1];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t row0 = ((int64_t)blockIdx.x * WPB + wave) * R;
-  uint32_t cut_hint = 0;
-  if (fa.state) cut_hint = __hip_atomic_load(&fa.state->cut, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
   v4f buf[R][NSTEP];
   if (row0 < n) {
@@ -200,7 +196,6 @@ __global__ __launch_bounds__(WPB * 64) void gemv_f32_oneshot_kernel(
     }
     const float v = wave_sum(s0 + s1);
     out = lane == r ? v : out;
-    if (fa.state && row0 + r < n) fuse_offer(fa, v, row0 + r, lane, cut_hint);
   }
   const int64_t row = row0 + lane;
   if (lane < R && row < n) scores[row] = out;

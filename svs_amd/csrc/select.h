@@ -31,18 +31,18 @@
 #include <stdint.h>
 
 #include "keys.h"
-#include "topk_state.h"
 
 namespace svs {
 
 constexpr int SEL_KMAX = 2048;    // path A handles k <= SEL_KMAX
 constexpr int SORT_CAP = 4096;    // keys sorted in LDS by one workgroup (32 KiB)
-constexpr int CAND_CAP = 32768;   // candidate keys per query (fused pre-filter or window filter)
+constexpr int CAND_CAP = 16384;   // survivors of the filter, per query
 constexpr int WBINS = 4096;       // window histogram bins
 constexpr uint32_t WTOP = 0xC000u;              // key16 of 2.0f
 constexpr uint32_t WBASE = WTOP - (WBINS - 1);  // key16 of ~2^-31
 constexpr int FA_THREADS = 512;   // histogram / filter workgroup
-constexpr int SORT_THREADS = 1024;
+constexpr int SORT_THREADS = 1024;  // global bitonic sort (path B) workgroup
+constexpr int FINAL_THREADS = 256;  // final kernel workgroup
 constexpr int RS_BINS = 2048;     // in-LDS radix select: 11 bits per pass
 constexpr int PICK_MAX_PER = 8;
 
@@ -112,20 +112,41 @@ __device__ __forceinline__ void pick_bucket(const uint32_t* hist, int bins, uint
   __syncthreads();
 }
 
-// ---- path A, launch 1.  grid = (blocks, nq) ---------------------------------
+// Each thread of the histogram / filter kernels owns SEL_VPT float4 groups of
+// the score vector, all requested before the first is used (the vector is
+// L2/MALL resident, so the pass is latency-, not bandwidth-bound).
+constexpr int SEL_VPT = 4;
+typedef float sel_v4f __attribute__((ext_vector_type(4)));
+
+// ---- path A, launch 1.  grid = (blocks, nq); score_stride % 4 == 0 ------------
 __global__ __launch_bounds__(FA_THREADS) void select_window_hist_kernel(
     const float* __restrict__ scores, int64_t n, int64_t score_stride,
     uint32_t* __restrict__ scratch) {
   __shared__ uint32_t lh[WBINS];
   const int qi = blockIdx.y;
   const float* s = scores + (int64_t)qi * score_stride;
+  const sel_v4f* s4 = (const sel_v4f*)s;
   uint32_t* hist = scratch + (int64_t)qi * SCR_WORDS + sizeof(SelHeader) / 4;
+  const int64_t n4 = (n + 3) >> 2;  // the allocation is padded to a multiple of 4
+  const int64_t base = ((int64_t)blockIdx.x * SEL_VPT) * FA_THREADS + threadIdx.x;
+  sel_v4f v[SEL_VPT];
+#pragma unroll
+  for (int j = 0; j < SEL_VPT; ++j) {
+    const int64_t i4 = base + (int64_t)j * FA_THREADS;
+    v[j] = i4 < n4 ? s4[i4] : (sel_v4f){0.f, 0.f, 0.f, 0.f};
+  }
   for (int i = threadIdx.x; i < WBINS; i += FA_THREADS) lh[i] = 0;
   __syncthreads();
-  const int64_t stride = (int64_t)gridDim.x * FA_THREADS;
-  for (int64_t i = (int64_t)blockIdx.x * FA_THREADS + threadIdx.x; i < n; i += stride) {
-    const int b = window_bin(score_key(s[i]));
-    if (b >= 0) atomicAdd(&lh[b], 1u);
+#pragma unroll
+  for (int j = 0; j < SEL_VPT; ++j) {
+    const int64_t i = (base + (int64_t)j * FA_THREADS) * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (i + e < n) {
+        const int b = window_bin(score_key(v[j][e]));
+        if (b >= 0) atomicAdd(&lh[b], 1u);
+      }
+    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < WBINS; i += FA_THREADS) {
@@ -141,8 +162,17 @@ __global__ __launch_bounds__(FA_THREADS) void select_window_filter_kernel(
   __shared__ uint32_t sh[FA_THREADS + 2];
   const int qi = blockIdx.y;
   const float* s = scores + (int64_t)qi * score_stride;
+  const sel_v4f* s4 = (const sel_v4f*)s;
   SelHeader* hdr = (SelHeader*)(scratch + (int64_t)qi * SCR_WORDS);
   const uint32_t* hist = scratch + (int64_t)qi * SCR_WORDS + sizeof(SelHeader) / 4;
+  const int64_t n4 = (n + 3) >> 2;
+  const int64_t base = ((int64_t)blockIdx.x * SEL_VPT) * FA_THREADS + threadIdx.x;
+  sel_v4f v[SEL_VPT];
+#pragma unroll
+  for (int j = 0; j < SEL_VPT; ++j) {   // requested before the histogram scan: the latency hides under it
+    const int64_t i4 = base + (int64_t)j * FA_THREADS;
+    v[j] = i4 < n4 ? s4[i4] : (sel_v4f){0.f, 0.f, 0.f, 0.f};
+  }
   uint32_t bstar, krank;
   pick_bucket<FA_THREADS>(hist, WBINS, k, sh, &bstar, &krank);
   if (bstar == 0xffffffffu) {  // fewer than k scores inside the window: exact fallback in the final kernel
@@ -151,26 +181,43 @@ __global__ __launch_bounds__(FA_THREADS) void select_window_filter_kernel(
   }
   uint64_t* cq = cand + (int64_t)qi * CAND_CAP;
   const int lane = threadIdx.x & 63;
-  const int64_t stride = (int64_t)gridDim.x * FA_THREADS;
-  const int64_t start = (int64_t)blockIdx.x * FA_THREADS + threadIdx.x;
-  const int64_t iters = (n + stride - 1) / stride;  // uniform trip count: ballots see whole waves
-  for (int64_t it = 0; it < iters; ++it) {
-    const int64_t i = start + it * stride;
-    uint32_t key = 0;
-    bool keep = false;
-    if (i < n) {
-      key = score_key(s[i]);
-      keep = window_bin(key) >= (int)bstar;
+#pragma unroll
+  for (int j = 0; j < SEL_VPT; ++j) {
+    const int64_t i = (base + (int64_t)j * FA_THREADS) * 4;
+    uint32_t key[4];
+    int cnt = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      key[e] = 0;
+      if (i + e < n) {
+        const uint32_t kk = score_key(v[j][e]);
+        if (window_bin(kk) >= (int)bstar) {
+          key[e] = kk;
+          ++cnt;
+        }
+      }
     }
-    const unsigned long long m = __ballot(keep);
+    // wave-aggregated append: one atomic per wave per group that has survivors
+    const unsigned long long m = __ballot(cnt > 0);
     if (m) {
-      uint32_t base = 0;
-      const int leader = __ffsll((long long)m) - 1;
-      if (lane == leader) base = atomicAdd(&hdr->n_cand, (uint32_t)__popcll(m));
-      base = __shfl(base, leader, 64);
-      if (keep) {
-        const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
-        if (slot < (uint32_t)CAND_CAP) cq[slot] = ((uint64_t)key << 32) | (uint32_t)i;
+      // exclusive prefix of cnt over the wave
+      int incl = cnt;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+      }
+      const int total = __shfl(incl, 63, 64);
+      uint32_t wbase = 0;
+      if (lane == 0) wbase = atomicAdd(&hdr->n_cand, (uint32_t)total);
+      wbase = __shfl(wbase, 0, 64);
+      uint32_t slot = wbase + (uint32_t)(incl - cnt);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (key[e]) {   // a real key is never 0 (score_key's minimum is 0x007fffff)
+          if (slot < (uint32_t)CAND_CAP) cq[slot] = ((uint64_t)key[e] << 32) | (uint32_t)(i + e);
+          ++slot;
+        }
       }
     }
   }
@@ -257,9 +304,8 @@ __device__ __forceinline__ uint64_t block_radix_select(KeyAt key_at, int64_t M, 
 }
 
 // ---- path A launch 3 / path D.  grid = nq, one workgroup per query ------------
-// mode 0: path A, candidates from the window filter; mode 1: path D (n <= SORT_CAP);
-// mode 2: path A, candidates from the pre-filter fused into the score kernel.
-__global__ __launch_bounds__(SORT_THREADS) void select_final_kernel(
+// mode 0: path A (candidates from the filter); mode 1: path D (n <= SORT_CAP).
+__global__ __launch_bounds__(FINAL_THREADS) void select_final_kernel(
     const float* __restrict__ scores, int64_t n, int64_t score_stride, int k_out, int count,
     int mode, uint32_t* __restrict__ scratch, const uint64_t* __restrict__ cand,
     int64_t row_offset, float* __restrict__ out_scores, int64_t* __restrict__ out_rows) {
@@ -276,18 +322,10 @@ __global__ __launch_bounds__(SORT_THREADS) void select_final_kernel(
     m = next_pow2((int)n < 2 ? 2 : (int)n);
     for (int i = threadIdx.x; i < m; i += blockDim.x) S[i] = i < n ? make_key(s[i], (uint32_t)i) : 0ull;
   } else {
-    const int scr_words = mode == 2 ? SEL_STATE_WORDS : SCR_WORDS;
+    SelHeader* hdr = (SelHeader*)(scratch + (int64_t)qi * SCR_WORDS);
     const uint64_t* cq = cand + (int64_t)qi * CAND_CAP;
-    uint32_t flag, n_cand;
-    if (mode == 2) {
-      const SelState* st = (const SelState*)(scratch + (int64_t)qi * SEL_STATE_WORDS);
-      flag = 0;
-      n_cand = st->n_cand;
-    } else {
-      const SelHeader* hdr = (const SelHeader*)(scratch + (int64_t)qi * SCR_WORDS);
-      flag = hdr->flag;
-      n_cand = hdr->n_cand;
-    }
+    const uint32_t flag = hdr->flag;
+    const uint32_t n_cand = hdr->n_cand;
     if (flag == 0 && n_cand <= (uint32_t)SORT_CAP) {
       m = next_pow2((int)n_cand < 2 ? 2 : (int)n_cand);
       for (int i = threadIdx.x; i < m; i += blockDim.x) S[i] = i < (int)n_cand ? cq[i] : 0ull;
@@ -314,8 +352,8 @@ __global__ __launch_bounds__(SORT_THREADS) void select_final_kernel(
     // leave the scratch zeroed for the next search on this context (after every
     // thread has read the header)
     __syncthreads();
-    uint32_t* w = scratch + (int64_t)qi * scr_words;
-    for (int i = threadIdx.x; i < scr_words; i += blockDim.x) w[i] = 0;
+    uint32_t* w = scratch + (int64_t)qi * SCR_WORDS;
+    for (int i = threadIdx.x; i < SCR_WORDS; i += blockDim.x) w[i] = 0;
   }
   __syncthreads();
   bitonic_sort_lds_desc(S, m);

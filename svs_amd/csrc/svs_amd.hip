@@ -206,11 +206,11 @@ int next_pow2_i64(int64_t v, int64_t* out) {
 
 // ---- score stage launch -----------------------------------------------------
 template <int NSTEP, int R, int WPB, bool NT>
-void launch_oneshot(const svs_index* idx, const float* q, float* scores, hipStream_t st, FuseArgs fa) {
+void launch_oneshot(const svs_index* idx, const float* q, float* scores, hipStream_t st) {
   const int64_t rows_per_block = (int64_t)R * WPB;
   const int64_t blocks = (idx->n + rows_per_block - 1) / rows_per_block;
   hipLaunchKernelGGL((gemv_f32_oneshot_kernel<NSTEP, R, WPB, NT, false>), dim3((unsigned)blocks), dim3(WPB * 64), 0, st,
-                     (const v4f*)idx->rows, (const v4f*)q, scores, idx->n, fa);
+                     (const v4f*)idx->rows, (const v4f*)q, scores, idx->n);
 }
 
 template <int NSTEP, int R, bool NT>
@@ -225,22 +225,20 @@ void launch_persistent(const svs_index* idx, const float* q, float* scores, hipS
 // Default geometry per row length (measured at NSTEP = 6: one-shot, 16-wave
 // workgroups, one row per wave, nontemporal loads: 7.2 TB/s on MI355X).
 // Short rows take several rows per wave so a wave still has >= 4 KiB in flight.
-// Returns true when the kernel honoured `fa` (the fused top-k pre-filter).
 template <int NSTEP>
-bool launch_rows(const svs_index* idx, const float* q, float* scores, hipStream_t st, int variant, FuseArgs fa) {
+void launch_rows(const svs_index* idx, const float* q, float* scores, hipStream_t st, int variant) {
   switch (variant) {
-    case 1: launch_persistent<NSTEP, 1, false>(idx, q, scores, st); return false;
-    case 2: launch_persistent<NSTEP, 2, true>(idx, q, scores, st); return false;
-    case 3: launch_oneshot<NSTEP, 2, 16, true>(idx, q, scores, st, fa); return true;
-    case 4: launch_oneshot<NSTEP, 1, 16, false>(idx, q, scores, st, fa); return true;
-    case 5: launch_oneshot<NSTEP, 1, 8, true>(idx, q, scores, st, fa); return true;
+    case 1: launch_persistent<NSTEP, 1, false>(idx, q, scores, st); return;
+    case 2: launch_persistent<NSTEP, 2, true>(idx, q, scores, st); return;
+    case 3: launch_oneshot<NSTEP, 2, 16, true>(idx, q, scores, st); return;
+    case 4: launch_oneshot<NSTEP, 1, 16, false>(idx, q, scores, st); return;
+    case 5: launch_oneshot<NSTEP, 1, 8, true>(idx, q, scores, st); return;
     default: break;
   }
-  if constexpr (NSTEP <= 2) launch_oneshot<NSTEP, 4, 16, true>(idx, q, scores, st, fa);
-  else if constexpr (NSTEP <= 4) launch_oneshot<NSTEP, 2, 16, true>(idx, q, scores, st, fa);
-  else if constexpr (NSTEP <= 6) launch_oneshot<NSTEP, 1, 16, true>(idx, q, scores, st, fa);
-  else launch_oneshot<NSTEP, 1, 8, true>(idx, q, scores, st, fa);
-  return true;
+  if constexpr (NSTEP <= 2) launch_oneshot<NSTEP, 4, 16, true>(idx, q, scores, st);
+  else if constexpr (NSTEP <= 4) launch_oneshot<NSTEP, 2, 16, true>(idx, q, scores, st);
+  else if constexpr (NSTEP <= 6) launch_oneshot<NSTEP, 1, 16, true>(idx, q, scores, st);
+  else launch_oneshot<NSTEP, 1, 8, true>(idx, q, scores, st);
 }
 
 template <int T>
@@ -252,23 +250,20 @@ void launch_generic(const svs_index* idx, const float* q, float* scores, hipStre
                      (const v4f*)idx->rows, q, scores, idx->n, idx->d, idx->ld / 4);
 }
 
-// q: device, d floats (unpadded); scores: device, n floats.  *fused tells the
-// caller whether the candidate list of `fa` was produced.
-int launch_scores(const svs_index* idx, const float* q, float* scores, hipStream_t st, FuseArgs fa, bool* fused) {
-  *fused = false;
+// q: device, d floats (unpadded); scores: device, n floats
+int launch_scores(const svs_index* idx, const float* q, float* scores, hipStream_t st) {
   if (idx->dtype != SVS_DTYPE_F32) return fail(SVS_ERR_UNSUPPORTED, "dtype %d not implemented yet", idx->dtype);
   const int variant = idx->variant.load();
-  if (variant == 6) fa.state = nullptr;  // A/B: unfused top-k
   const bool q_aligned = (((uintptr_t)q) & 15) == 0;
   if (idx->ld == idx->d && idx->ld % 256 == 0 && q_aligned) {
     switch (idx->ld / 256) {
-      case 1: *fused = launch_rows<1>(idx, q, scores, st, variant, fa) && fa.state; return SVS_OK;
-      case 2: *fused = launch_rows<2>(idx, q, scores, st, variant, fa) && fa.state; return SVS_OK;
-      case 3: *fused = launch_rows<3>(idx, q, scores, st, variant, fa) && fa.state; return SVS_OK;
-      case 4: *fused = launch_rows<4>(idx, q, scores, st, variant, fa) && fa.state; return SVS_OK;
-      case 6: *fused = launch_rows<6>(idx, q, scores, st, variant, fa) && fa.state; return SVS_OK;
-      case 8: *fused = launch_rows<8>(idx, q, scores, st, variant, fa) && fa.state; return SVS_OK;
-      case 12: *fused = launch_rows<12>(idx, q, scores, st, variant, fa) && fa.state; return SVS_OK;
+      case 1: launch_rows<1>(idx, q, scores, st, variant); return SVS_OK;
+      case 2: launch_rows<2>(idx, q, scores, st, variant); return SVS_OK;
+      case 3: launch_rows<3>(idx, q, scores, st, variant); return SVS_OK;
+      case 4: launch_rows<4>(idx, q, scores, st, variant); return SVS_OK;
+      case 6: launch_rows<6>(idx, q, scores, st, variant); return SVS_OK;
+      case 8: launch_rows<8>(idx, q, scores, st, variant); return SVS_OK;
+      case 12: launch_rows<12>(idx, q, scores, st, variant); return SVS_OK;
       default: break;
     }
   }
@@ -287,10 +282,10 @@ int launch_scores(const svs_index* idx, const float* q, float* scores, hipStream
 int enqueue_search(svs_index* idx, Ctx* c, const float* q_dev, int nq, int k, int count,
                    float* out_s, int64_t* out_r, hipStream_t st) {
   const int64_t n = idx->n;
+  const int64_t sstride = (n + 3) & ~(int64_t)3;  // float4-aligned score vectors
   int rc;
-  if ((rc = grow_dev(&c->scores, &c->scores_cap, (size_t)nq * (size_t)n)) != SVS_OK) return rc;
+  if ((rc = grow_dev(&c->scores, &c->scores_cap, (size_t)nq * (size_t)sstride)) != SVS_OK) return rc;
   const bool path_a = k > 0 && n > SORT_CAP && count <= SEL_KMAX;
-  static_assert(SEL_STATE_WORDS == SCR_WORDS, "both top-k scratch layouts share one allocation");
   if (path_a && (size_t)nq > c->hist_cap) {
     if (c->hist) HIP_TRY(hipFree(c->hist));
     if (c->cand) HIP_TRY(hipFree(c->cand));
@@ -311,38 +306,30 @@ int enqueue_search(svs_index* idx, Ctx* c, const float* q_dev, int nq, int k, in
     HIP_TRY(hipEventCreate(&ev.e2));
     HIP_TRY(hipEventRecord(ev.e0, st));
   }
-  bool fused_all = true;
   for (int qi = 0; qi < nq; ++qi) {
-    FuseArgs fa{nullptr, nullptr, 0, 0};
-    if (path_a) fa = FuseArgs{(SelState*)(c->hist + (size_t)qi * SEL_STATE_WORDS), c->cand + (size_t)qi * CAND_CAP,
-                              (uint32_t)count, (uint32_t)CAND_CAP};
-    bool fused = false;
-    rc = launch_scores(idx, q_dev + (size_t)qi * idx->d, c->scores + (size_t)qi * n, st, fa, &fused);
+    rc = launch_scores(idx, q_dev + (size_t)qi * idx->d, c->scores + (size_t)qi * sstride, st);
     if (rc != SVS_OK) return rc;
-    fused_all = fused_all && fused;
   }
   if (timed) HIP_TRY(hipEventRecord(ev.e1, st));
 
   if (k > 0) {
     if (n <= SORT_CAP) {
-      hipLaunchKernelGGL(select_final_kernel, dim3(nq), dim3(SORT_THREADS), 0, st, c->scores, n, n, k,
+      hipLaunchKernelGGL(select_final_kernel, dim3(nq), dim3(FINAL_THREADS), 0, st, c->scores, n, sstride, k,
                          count, 1, (uint32_t*)nullptr, (const uint64_t*)nullptr, idx->row_offset, out_s, out_r);
-    } else if (path_a && fused_all) {
-      hipLaunchKernelGGL(select_final_kernel, dim3(nq), dim3(SORT_THREADS), 0, st, c->scores, n, n, k, count, 2,
-                         c->hist, c->cand, idx->row_offset, out_s, out_r);
     } else if (path_a) {
-      const int blocks = (int)std::min<int64_t>(std::max<int64_t>(n / 8192, 1), 1024);
-      hipLaunchKernelGGL(select_window_hist_kernel, dim3(blocks, nq), dim3(FA_THREADS), 0, st, c->scores, n, n, c->hist);
-      hipLaunchKernelGGL(select_window_filter_kernel, dim3(blocks, nq), dim3(FA_THREADS), 0, st, c->scores, n, n,
+      const int64_t per_block = (int64_t)FA_THREADS * SEL_VPT * 4;
+      const unsigned blocks = (unsigned)((n + per_block - 1) / per_block);
+      hipLaunchKernelGGL(select_window_hist_kernel, dim3(blocks, nq), dim3(FA_THREADS), 0, st, c->scores, n, sstride, c->hist);
+      hipLaunchKernelGGL(select_window_filter_kernel, dim3(blocks, nq), dim3(FA_THREADS), 0, st, c->scores, n, sstride,
                          (uint32_t)count, c->hist, c->cand);
-      hipLaunchKernelGGL(select_final_kernel, dim3(nq), dim3(SORT_THREADS), 0, st, c->scores, n, n, k, count, 0,
+      hipLaunchKernelGGL(select_final_kernel, dim3(nq), dim3(FINAL_THREADS), 0, st, c->scores, n, sstride, k, count, 0,
                          c->hist, c->cand, idx->row_offset, out_s, out_r);
     } else {
       int64_t npad;
       next_pow2_i64(n, &npad);
       if ((rc = grow_dev(&c->keys, &c->keys_cap, (size_t)nq * (size_t)npad)) != SVS_OK) return rc;
       int gb = (int)std::min<int64_t>((npad + 255) / 256, 4096);
-      hipLaunchKernelGGL(keys_build_kernel, dim3(gb, nq), dim3(256), 0, st, c->scores, n, n, npad, c->keys);
+      hipLaunchKernelGGL(keys_build_kernel, dim3(gb, nq), dim3(256), 0, st, c->scores, n, sstride, npad, c->keys);
       const int64_t chunk = std::min<int64_t>(npad, SORT_CAP);
       hipLaunchKernelGGL(bitonic_local_kernel, dim3((unsigned)(npad / chunk), nq), dim3(SORT_THREADS), 0, st, c->keys, npad, 0, 1);
       for (int64_t size = 2 * (int64_t)SORT_CAP; size <= npad; size <<= 1) {
@@ -588,7 +575,7 @@ int32_t svs_index_search_device(svs_index* idx, const float* dev_queries, int32_
   if ((rc = ctx_acquire(idx, st, false, &c)) != SVS_OK) return rc;
   struct CtxGuard { svs_index* i; Ctx* c; ~CtxGuard() { ctx_release(i, c); } } cg{idx, c};
   // growing scratch frees buffers that earlier work on this stream may still read
-  const size_t need_scores = (size_t)nq * (size_t)idx->n;
+  const size_t need_scores = (size_t)nq * (size_t)((idx->n + 3) & ~(int64_t)3);
   if (c->async_pending && (need_scores > c->scores_cap || (size_t)nq > c->hist_cap)) HIP_TRY(hipStreamSynchronize(st));
   rc = enqueue_search(idx, c, dev_queries, nq, k, count, dev_out_scores, dev_out_rows, st);
   c->last_stream = st;
@@ -607,10 +594,9 @@ int32_t svs_index_scores(svs_index* idx, const float* query, int32_t d, float* o
   if ((rc = ctx_acquire(idx, nullptr, true, &c)) != SVS_OK) return rc;
   struct CtxGuard { svs_index* i; Ctx* c; ~CtxGuard() { ctx_release(i, c); } } cg{idx, c};
   if ((rc = grow_dev(&c->q_dev, &c->q_cap, (size_t)d)) != SVS_OK) return rc;
-  if ((rc = grow_dev(&c->scores, &c->scores_cap, (size_t)idx->n)) != SVS_OK) return rc;
+  if ((rc = grow_dev(&c->scores, &c->scores_cap, (size_t)((idx->n + 3) & ~(int64_t)3))) != SVS_OK) return rc;
   HIP_TRY(hipMemcpyAsync(c->q_dev, query, (size_t)d * sizeof(float), hipMemcpyHostToDevice, c->stream));
-  bool fused = false;
-  if ((rc = launch_scores(idx, c->q_dev, c->scores, c->stream, FuseArgs{nullptr, nullptr, 0, 0}, &fused)) != SVS_OK) return rc;
+  if ((rc = launch_scores(idx, c->q_dev, c->scores, c->stream)) != SVS_OK) return rc;
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(out_scores, c->scores, (size_t)idx->n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -656,7 +642,7 @@ int32_t svs_index_get_timing(svs_index* idx, svs_timing_t* out) {
 
 int32_t svs_index_set_variant(svs_index* idx, int32_t variant) {
   if (!idx) return fail(SVS_ERR_INVALID, "null index");
-  if (variant < 0 || variant > 6) return fail(SVS_ERR_INVALID, "unknown variant %d", variant);
+  if (variant < 0 || variant > 5) return fail(SVS_ERR_INVALID, "unknown variant %d", variant);
   idx->variant.store(variant);
   return SVS_OK;
 }

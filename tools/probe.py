@@ -20,7 +20,7 @@ del m
 torch.cuda.empty_cache()
 qh = q.cpu().numpy()
 bytes_q = n * d * 4
-for variant in (0, 6, 3, 5, 0, 6):
+for variant in (0, 3, 5, 0):
     idx.set_variant(variant)
     for _ in range(3):
         idx.search(qh, 100)
