@@ -65,7 +65,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=20)
     ap.add_argument("--latency-iters", type=int, default=200)
-    ap.add_argument("--inflight", type=int, default=2,
+    ap.add_argument("--inflight", type=int, default=1,
                     help="searches kept in flight on separate HIP streams (2 lets the top-k "
                          "stage of query i overlap the score stage of query i+1)")
     args = ap.parse_args()
@@ -183,6 +183,23 @@ def main():
             lats.append((time.perf_counter() - a) * 1e3)
         lat_ms = float(np.median(lats))
 
+    # HBM traffic of the dominant kernel from the committed PMC passes (separate
+    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950
+    # corrections applied by tools/summarize_prof.py); only quoted for the
+    # configuration it was collected on.
+    traffic, traffic_src = None, None
+    if rank == 0 and n_local == 1_000_000 and d == 1536:
+        import glob
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")))[::-1]:
+            try:
+                pm = json.load(open(f))["pmc"]
+                kn = [v for kname, v in pm.items() if "gemv_f32" in kname and "hbm_bytes_per_launch" in v]
+                if kn:
+                    traffic, traffic_src = kn[0]["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
+                    break
+            except Exception:
+                continue
+
     out = None
     if rank == 0:
         kernel_ms = score_ms / max(launches, 1)
@@ -213,7 +230,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": "gemv_f32 score stage",
                 "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK, "traffic": None,
+                "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": launches,
                 "avg_launch_ms": kernel_ms,
             },

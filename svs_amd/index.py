@@ -101,6 +101,13 @@ class DeviceIndex:
             self._lib.svs_index_retain(h)
             return h
 
+    def share(self) -> "DeviceIndex":
+        """A second owner of the same HBM copy (its own reference): what an
+        in-flight AsyncKB search holds so that ``invalidate()`` on another task
+        cannot pull the corpus from under it (reference semantics: the closure
+        keeps the numpy arrays alive, src/svs/kb.py:1180-1190)."""
+        return DeviceIndex(None, _handle=self._pinned_handle())
+
     # -- search -----------------------------------------------------------
     def search_batch(self, queries: np.ndarray, n: int) -> Tuple[np.ndarray, np.ndarray]:
         """Top-n for each row of ``queries`` (nq, D).  Returns

@@ -1,0 +1,423 @@
+"""
+Host-side mirror of the reference's ``KB`` / ``AsyncKB`` **for the retrieve()
+path only** (SURVEY.md section 8(a) rows A1, A6, A7, A8).
+
+The reference's Python files do not travel to the GPU box, so this module gives
+the parity tests (and users without the reference installed) the same surface:
+``KB(path, embedding_func)``, ``bulk_add_docs()``, ``bulk_del_docs()``,
+``retrieve(query, n) -> List[Retrieval]``, ``close()``, ``len()`` -- same
+names, argument meaning and error behaviour as reference src/svs/kb.py:1407-1640
+(sync) and :925-1206 (async).  Storage is a plain SQLite file with the
+reference's schema v1 table layout (src/svs/kb.py:64-113), so a database
+written by either implementation opens in the other; the graph / key-value /
+hierarchy features of the reference are NOT rebuilt (out of scope, pure SQL).
+
+The similarity search itself (``superheavy()``, src/svs/kb.py:1622-1627) is
+``DeviceEmbeddingsMatrix.search`` -> HIP.  There is no numpy fallback.
+"""
+from __future__ import annotations
+
+import asyncio
+import json
+import logging
+import sqlite3
+import struct
+import threading
+from contextlib import asynccontextmanager, contextmanager
+from typing import Any, Awaitable, Callable, Dict, Iterator, List, Optional, Tuple
+
+import numpy as np
+
+from .index import DeviceIndex
+from .matrix import DeviceEmbeddingsMatrix
+
+_LOG = logging.getLogger(__name__)
+
+EmbeddingFunc = Callable[[List[str]], Awaitable[List[List[float]]]]   # reference src/svs/types.py:12
+
+EMBEDDING_MAGNITUDE_TOLERANCE = 0.001   # reference src/svs/kb.py:58
+BULK_EMBEDDING_CHUNK_SIZE = 200         # reference src/svs/kb.py:52
+SCHEMA_VERSION = 1                      # reference src/svs/kb.py:61
+
+# Table layout of the reference's schema v1 (data format, src/svs/kb.py:64-113).
+_SCHEMA = [
+    "CREATE TABLE IF NOT EXISTS keyval (id INTEGER PRIMARY KEY, key TEXT NOT NULL UNIQUE, val ANY NOT NULL) STRICT",
+    "CREATE TABLE IF NOT EXISTS keyval_user (id INTEGER PRIMARY KEY, key TEXT NOT NULL UNIQUE, val ANY NOT NULL) STRICT",
+    "CREATE TABLE IF NOT EXISTS embeddings (id INTEGER PRIMARY KEY, embedding BLOB NOT NULL) STRICT",
+    "CREATE TABLE IF NOT EXISTS docs (id INTEGER PRIMARY KEY, parent_id INTEGER REFERENCES docs(id), "
+    "level INTEGER NOT NULL, text TEXT NOT NULL, embedding INTEGER REFERENCES embeddings(id), meta TEXT) STRICT",
+    "CREATE INDEX IF NOT EXISTS idx_docs_parent_id ON docs(parent_id)",
+    "CREATE INDEX IF NOT EXISTS idx_docs_level ON docs(level)",
+    "CREATE INDEX IF NOT EXISTS idx_docs_embedding ON docs(embedding)",
+    "CREATE TABLE IF NOT EXISTS edges (id INTEGER PRIMARY KEY, a INTEGER REFERENCES docs(id) NOT NULL, "
+    "b INTEGER REFERENCES docs(id) NOT NULL, r INTEGER REFERENCES docs(id) NOT NULL, w REAL, d INTEGER NOT NULL) STRICT",
+    "CREATE UNIQUE INDEX IF NOT EXISTS idx_edges_abr ON edges(a, b, r)",
+    "CREATE INDEX IF NOT EXISTS idx_edges_a ON edges(a)",
+    "CREATE INDEX IF NOT EXISTS idx_edges_b ON edges(b)",
+    "CREATE INDEX IF NOT EXISTS idx_edges_r ON edges(r)",
+    "CREATE INDEX IF NOT EXISTS idx_edges_d ON edges(d)",
+]
+
+
+def embedding_to_bytes(embedding: List[float]) -> bytes:
+    """Little-endian f32 BLOB codec, reference src/svs/embeddings/util.py:15-16."""
+    return np.asarray(embedding, dtype="<f4").tobytes() if len(embedding) else b""
+
+
+def embedding_from_bytes(blob: bytes) -> List[float]:
+    """Reference src/svs/embeddings/util.py:19-23."""
+    assert len(blob) % 4 == 0
+    return [float(x) for x in np.frombuffer(blob, dtype="<f4")]
+
+
+def check_magnitude(vectors: List[List[float]], tolerance: float = EMBEDDING_MAGNITUDE_TOLERANCE) -> None:
+    """Unit-norm guard, reference src/svs/embeddings/util.py:34-39 (f32 norms).
+    The HIP kernels compute a plain dot product and do NOT re-normalise, exactly
+    like the reference, so this guard is what makes the score a cosine."""
+    v = np.array(vectors, dtype=np.float32)
+    if v.ndim != 2:
+        raise ValueError("embedding function must return a list of equal-length vectors")
+    mags = np.sqrt((v * v).sum(axis=1))
+    if (np.abs(mags - 1.0) > tolerance).any():
+        raise ValueError("embedding magnitude out of spec")
+
+
+class _Store:
+    """Minimal SQLite access for the retrieve() path.  One connection, used from
+    one thread at a time (callers serialise, as the reference does with its
+    asyncio.Lock -- src/svs/kb.py:942-945)."""
+
+    def __init__(self, path: str):
+        self.path = str(path)
+        self.conn = sqlite3.connect(self.path, isolation_level=None, check_same_thread=False)
+        self.conn.execute("PRAGMA foreign_keys = ON")
+        self._tx = threading.RLock()
+        with self.transaction():
+            for stmt in _SCHEMA:
+                self.conn.execute(stmt)
+            row = self.conn.execute("SELECT val FROM keyval WHERE key = 'schema_version'").fetchone()
+            if row is None:
+                self.conn.execute("INSERT INTO keyval (key, val) VALUES ('schema_version', ?)", (SCHEMA_VERSION,))
+            elif row[0] != SCHEMA_VERSION:
+                raise RuntimeError(f"unsupported schema version {row[0]}")
+
+    @contextmanager
+    def transaction(self):
+        """All-or-nothing, like the reference's ``with db as q`` (src/svs/kb.py:806-817)."""
+        with self._tx:
+            self.conn.execute("BEGIN")
+            try:
+                yield self
+            except BaseException:
+                self.conn.execute("ROLLBACK")
+                raise
+            else:
+                self.conn.execute("COMMIT")
+
+    def close(self) -> None:
+        self.conn.close()
+
+    # -- docs ---------------------------------------------------------------
+    def add_doc(self, text: str, parent_id: Optional[int], meta: Optional[Dict[str, Any]]) -> int:
+        level = 0
+        if parent_id is not None:
+            row = self.conn.execute("SELECT level FROM docs WHERE id = ?", (parent_id,)).fetchone()
+            if row is None:
+                raise ValueError(f"invalid parent_id: {parent_id}")
+            level = row[0] + 1
+        cur = self.conn.execute(
+            "INSERT INTO docs (parent_id, level, text, embedding, meta) VALUES (?, ?, ?, NULL, ?)",
+            (parent_id, level, text, json.dumps(meta) if meta is not None else None))
+        return int(cur.lastrowid)
+
+    def set_doc_embedding(self, doc_id: int, blob: bytes) -> None:
+        cur = self.conn.execute("INSERT INTO embeddings (embedding) VALUES (?)", (blob,))
+        res = self.conn.execute("UPDATE docs SET embedding = ? WHERE id = ?", (cur.lastrowid, doc_id))
+        if res.rowcount != 1:
+            raise KeyError(doc_id)
+
+    def del_doc(self, doc_id: int) -> None:
+        row = self.conn.execute("SELECT embedding FROM docs WHERE id = ?", (doc_id,)).fetchone()
+        if row is None:
+            raise KeyError(doc_id)
+        self.conn.execute("DELETE FROM docs WHERE id = ?", (doc_id,))
+        if row[0] is not None:
+            self.conn.execute("DELETE FROM embeddings WHERE id = ?", (row[0],))
+
+    def count_docs(self) -> int:
+        return int(self.conn.execute("SELECT COUNT(*) FROM docs").fetchone()[0])
+
+    def fetch_doc_for_embedding(self, emb_id: int) -> Dict[str, Any]:
+        """The two SELECTs per result of reference src/svs/kb.py:1633-1634, as one
+        join; the record has the shape of fetch_doc(include_embedding=False)
+        (src/svs/kb.py:464-473)."""
+        row = self.conn.execute(
+            "SELECT id, parent_id, level, text, embedding, meta FROM docs WHERE embedding = ?", (emb_id,)).fetchone()
+        if row is None:
+            raise KeyError(emb_id)
+        return {"id": row[0], "parent_id": row[1], "level": row[2], "text": row[3],
+                "embedding": row[4] is not None, "meta": json.loads(row[5]) if row[5] is not None else None}
+
+    # -- A7: the producer of the matrix ---------------------------------------
+    def build_embeddings_matrix(self) -> Tuple[np.ndarray, np.ndarray]:
+        """Same contract as reference src/svs/kb.py:573-618 -- f32 (n, m) C-contiguous
+        matrix + i64 ids, rows in ``SELECT id, embedding FROM embeddings`` order, m
+        from the first row, empty table -> shape (0, 0) -- but each BLOB is viewed
+        with ``np.frombuffer`` straight into the row instead of
+        ``struct.unpack`` -> python list -> assign (the reference's 98.7 s cold
+        start at 1M rows)."""
+        n = int(self.conn.execute("SELECT COUNT(*) FROM embeddings").fetchone()[0])
+        first = self.conn.execute("SELECT embedding FROM embeddings LIMIT 1").fetchone()
+        m = len(first[0]) // 4 if first is not None else 0
+        matrix = np.zeros((n, m), dtype=np.float32)
+        lookup = np.zeros(n, dtype=np.int64)
+        i = -1
+        for i, (emb_id, blob) in enumerate(self.conn.execute("SELECT id, embedding FROM embeddings")):
+            assert len(blob) == m * 4
+            matrix[i] = np.frombuffer(blob, dtype="<f4")
+            lookup[i] = emb_id
+        assert i == n - 1
+        return matrix, lookup
+
+
+def _build_from_store(store: _Store) -> Tuple[np.ndarray, np.ndarray]:
+    with store.transaction():
+        return store.build_embeddings_matrix()
+
+
+class KB:
+    """Sync knowledge base, retrieve() path only.  Mirrors reference
+    src/svs/kb.py:1407-1640."""
+
+    def __init__(self, local_path: str, embedding_func: Optional[EmbeddingFunc] = None,
+                 device: int = 0, index_factory: Callable[..., Any] = DeviceIndex):
+        if embedding_func is None:
+            raise RuntimeError("No embedding function. You must pass the embedding function you want to use.")
+        self.embedding_func = embedding_func
+        self.db: Optional[_Store] = _Store(local_path)
+        self.embeddings_matrix = DeviceEmbeddingsMatrix(device=device, builder=_build_from_store,
+                                                        index_factory=index_factory)
+        self._loop = asyncio.new_event_loop()
+
+    # -- embedding helpers (A8) -------------------------------------------------
+    def _embed(self, texts: List[str]) -> List[List[float]]:
+        awaitable = self.embedding_func(texts)
+        assert asyncio.iscoroutine(awaitable)
+        vectors = self._loop.run_until_complete(awaitable)
+        check_magnitude(vectors)
+        return vectors
+
+    def __len__(self) -> int:
+        assert self.db is not None
+        with self.db.transaction():
+            return self.db.count_docs()
+
+    def load(self) -> None:
+        """Reference ``load()``: build the matrix now instead of at the first
+        retrieve() (src/svs/kb.py:964-967 async twin)."""
+        assert self.db is not None
+        self.embeddings_matrix.get_sync(self.db)
+
+    def close(self) -> None:
+        if self.db is not None:
+            self.db.close()
+            self.db = None
+            self.embeddings_matrix.invalidate()
+        if not self._loop.is_closed():
+            self._loop.close()
+
+    @contextmanager
+    def bulk_add_docs(self) -> Iterator[Callable[..., int]]:
+        """Reference src/svs/kb.py:1486-1524: docs are inserted inside ONE
+        transaction, embeddings are fetched in chunks of 200 at exit, then the
+        cached matrix is invalidated."""
+        assert self.db is not None
+        with self.db.transaction():
+            live = True
+            pending: List[Tuple[int, str]] = []
+
+            def add_doc(text: str, parent_id: Optional[int] = None, meta: Optional[Dict[str, Any]] = None,
+                        no_embedding: bool = False) -> int:
+                assert live, "You may not call this function outside of the context manager!"
+                doc_id = self.db.add_doc(text, parent_id, meta)
+                if not no_embedding:
+                    pending.append((doc_id, text))
+                return doc_id
+
+            try:
+                yield add_doc
+            finally:
+                live = False
+            for c0 in range(0, len(pending), BULK_EMBEDDING_CHUNK_SIZE):
+                chunk = pending[c0:c0 + BULK_EMBEDDING_CHUNK_SIZE]
+                vectors = self._embed([t for _, t in chunk])
+                for (doc_id, _), vec in zip(chunk, vectors):
+                    self.db.set_doc_embedding(doc_id, embedding_to_bytes(vec))
+            self.embeddings_matrix.invalidate()
+
+    @contextmanager
+    def bulk_del_docs(self) -> Iterator[Callable[[int], None]]:
+        """Reference src/svs/kb.py:1526-1542."""
+        assert self.db is not None
+        with self.db.transaction():
+            live = True
+
+            def del_doc(doc_id: int) -> None:
+                assert live, "You may not call this function outside of the context manager!"
+                self.db.del_doc(doc_id)
+
+            try:
+                yield del_doc
+            finally:
+                live = False
+            self.embeddings_matrix.invalidate()
+
+    def retrieve(self, query: str, n: int) -> List[Dict[str, Any]]:
+        """Reference src/svs/kb.py:1608-1640.  Same four log lines, same result
+        shape (``Retrieval``: {'score': float, 'doc': DocumentRecord})."""
+        _LOG.info(f"retrieving {n} documents with query string: {query}")
+        assert self.db is not None
+        self.embeddings_matrix.get_sync(self.db)
+        query_vec = np.array(self._embed([query])[0], dtype=np.float32)
+        _LOG.info("got embedding for query!")
+        emb_ids = self.embeddings_matrix.search(query_vec, n)          # superheavy(): HIP
+        _LOG.info(f"computed {self.embeddings_matrix.index.shape[0]} cosine similarities")
+        with self.db.transaction():
+            res = [{"score": score, "doc": self.db.fetch_doc_for_embedding(emb_id)} for score, emb_id in emb_ids]
+        _LOG.info(f"retrieved top {n} documents")
+        return res
+
+
+class AsyncKB:
+    """Async twin (reference src/svs/kb.py:925-1206): the matrix is fetched under
+    the lock, ``superheavy`` runs on an executor thread OUTSIDE the lock
+    (:1184-1190), so concurrent retrieve() calls search the same handle
+    concurrently -- the C ABI is re-entrant for exactly this."""
+
+    def __init__(self, local_path: str, embedding_func: Optional[EmbeddingFunc] = None,
+                 device: int = 0, index_factory: Callable[..., Any] = DeviceIndex):
+        if embedding_func is None:
+            raise RuntimeError("No embedding function. You must pass the embedding function you want to use.")
+        self.embedding_func = embedding_func
+        self._path = local_path
+        self.db: Optional[_Store] = None
+        self._lock: Optional[asyncio.Lock] = None
+        self.embeddings_matrix = DeviceEmbeddingsMatrix(device=device, builder=_build_from_store,
+                                                        index_factory=index_factory)
+
+    def _get_lock(self) -> asyncio.Lock:
+        if self._lock is None:
+            self._lock = asyncio.Lock()
+        return self._lock
+
+    async def _ensure_db(self) -> _Store:
+        if self.db is None:
+            loop = asyncio.get_running_loop()
+            self.db = await loop.run_in_executor(None, lambda: _Store(self._path))
+        return self.db
+
+    async def _embed(self, texts: List[str]) -> List[List[float]]:
+        vectors = await self.embedding_func(texts)
+        check_magnitude(vectors)
+        return vectors
+
+    async def load(self) -> None:
+        async with self._get_lock():
+            db = await self._ensure_db()
+            await self.embeddings_matrix.get(db)
+
+    async def close(self) -> None:
+        async with self._get_lock():
+            if self.db is not None:
+                self.db.close()
+                self.db = None
+            self.embeddings_matrix.invalidate()
+
+    async def count(self) -> int:
+        async with self._get_lock():
+            db = await self._ensure_db()
+            with db.transaction():
+                return db.count_docs()
+
+    @asynccontextmanager
+    async def bulk_add_docs(self):
+        async with self._get_lock():
+            db = await self._ensure_db()
+            pending: List[Tuple[int, str]] = []
+            live = True
+            db.conn.execute("BEGIN")
+            try:
+                async def add_doc(text: str, parent_id: Optional[int] = None,
+                                  meta: Optional[Dict[str, Any]] = None, no_embedding: bool = False) -> int:
+                    assert live, "You may not call this function outside of the context manager!"
+                    doc_id = db.add_doc(text, parent_id, meta)
+                    if not no_embedding:
+                        pending.append((doc_id, text))
+                    return doc_id
+                try:
+                    yield add_doc
+                finally:
+                    live = False
+                for c0 in range(0, len(pending), BULK_EMBEDDING_CHUNK_SIZE):
+                    chunk = pending[c0:c0 + BULK_EMBEDDING_CHUNK_SIZE]
+                    vectors = await self._embed([t for _, t in chunk])
+                    for (doc_id, _), vec in zip(chunk, vectors):
+                        db.set_doc_embedding(doc_id, embedding_to_bytes(vec))
+            except BaseException:
+                db.conn.execute("ROLLBACK")
+                raise
+            else:
+                db.conn.execute("COMMIT")
+            self.embeddings_matrix.invalidate()
+
+    @asynccontextmanager
+    async def bulk_del_docs(self):
+        async with self._get_lock():
+            db = await self._ensure_db()
+            live = True
+            db.conn.execute("BEGIN")
+            try:
+                async def del_doc(doc_id: int) -> None:
+                    assert live, "You may not call this function outside of the context manager!"
+                    db.del_doc(doc_id)
+                try:
+                    yield del_doc
+                finally:
+                    live = False
+            except BaseException:
+                db.conn.execute("ROLLBACK")
+                raise
+            else:
+                db.conn.execute("COMMIT")
+            self.embeddings_matrix.invalidate()
+
+    async def retrieve(self, query: str, n: int) -> List[Dict[str, Any]]:
+        """Reference src/svs/kb.py:1171-1206."""
+        _LOG.info(f"retrieving {n} documents with query string: {query}")
+        loop = asyncio.get_running_loop()
+        async with self._get_lock():
+            db = await self._ensure_db()
+            await self.embeddings_matrix.get(db)
+            # own a reference now: a later invalidate() must not affect this search
+            idx, lookup = self.embeddings_matrix.hold()
+        try:
+            query_vec = np.array((await self._embed([query]))[0], dtype=np.float32)
+            _LOG.info("got embedding for query!")
+
+            def superheavy() -> List[Tuple[float, int]]:
+                return [(score, int(lookup[row])) for score, row in idx.search(query_vec, n)]
+
+            emb_ids = await loop.run_in_executor(None, superheavy)
+            _LOG.info(f"computed {idx.shape[0]} cosine similarities")
+        finally:
+            idx.release()
+        async with self._get_lock():
+            db = await self._ensure_db()
+
+            def heavy() -> List[Dict[str, Any]]:
+                with db.transaction():
+                    return [{"score": s, "doc": db.fetch_doc_for_embedding(e)} for s, e in emb_ids]
+
+            res = await loop.run_in_executor(None, heavy)
+        _LOG.info(f"retrieved top {n} documents")
+        return res

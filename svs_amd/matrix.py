@@ -1,0 +1,243 @@
+"""
+The seam between SVS's KB classes and the HIP backend.
+
+``DeviceEmbeddingsMatrix`` has the surface of the reference's
+``_EmbeddingsMatrix`` (src/svs/kb.py:856-893: ``get_sync`` / ``get`` /
+``invalidate``) but what it caches is an HBM-resident ``DeviceIndex`` next to the
+``emb_id_lookup`` array.  Two ways to put it under the reference's
+``retrieve()``:
+
+* the explicit 3-line patch of INTEGRATION.md (``superheavy()`` calls
+  ``matrix.search(query_vec, n)``), or
+* ``attach(kb)``: no reference line changes.  ``get_sync`` then returns a
+  ``DeviceMatrixView`` in place of the numpy matrix; the reference's own
+  ``np.dot(embeddings_matrix, query_vec)`` (kb.py:1623) and
+  ``np.argpartition(scores, -top_k)`` (util.py:202) are routed to the device
+  through NumPy's ``__array_function__`` protocol, and ``float(scores[i])``
+  (util.py:203) reads the scores the device returned.  The reference's
+  ``sorted(..., reverse=True)`` then orders them exactly as before.
+"""
+from __future__ import annotations
+
+import asyncio
+import logging
+import threading
+from typing import Any, Callable, List, Optional, Tuple
+
+import numpy as np
+
+from .index import DeviceIndex
+
+_LOG = logging.getLogger(__name__)
+
+MatrixBuilder = Callable[[Any], Tuple[np.ndarray, np.ndarray]]
+
+
+def _default_builder(db) -> Tuple[np.ndarray, np.ndarray]:
+    """``with db as q: q.build_embeddings_matrix()`` -- the reference's own
+    producer (src/svs/kb.py:872-873)."""
+    with db as q:
+        return q.build_embeddings_matrix()
+
+
+class DeviceEmbeddingsMatrix:
+    """Lazy cache of (DeviceIndex, emb_id_lookup); drop-in for
+    ``svs.kb._EmbeddingsMatrix``."""
+
+    def __init__(self, device: int = 0, builder: MatrixBuilder = _default_builder,
+                 index_factory: Callable[..., Any] = DeviceIndex, keep_host_matrix: bool = True,
+                 view: bool = False):
+        self.device = device
+        self._builder = builder
+        self._index_factory = index_factory
+        self._keep_host = keep_host_matrix
+        self._view = view
+        self._mu = threading.Lock()
+        self.index: Optional[Any] = None
+        self.embeddings_matrix: Optional[np.ndarray] = None   # host copy (pairwise path), optional
+        self.emb_id_lookup: Optional[np.ndarray] = None
+
+    # -- reference surface ------------------------------------------------
+    def invalidate(self) -> None:
+        """src/svs/kb.py:861-864.  In-flight searches keep the HBM copy alive
+        (the handle is reference counted)."""
+        _LOG.info("invalidating cached vectors; they'll be re-built next time you `retrieve()`")
+        with self._mu:
+            idx, self.index = self.index, None
+            self.embeddings_matrix = None
+            self.emb_id_lookup = None
+        if idx is not None:
+            idx.release()
+
+    def _install(self, matrix: np.ndarray, lookup: np.ndarray):
+        idx = self._index_factory(matrix, device=self.device)
+        with self._mu:
+            self.index = idx
+            self.emb_id_lookup = lookup
+            self.embeddings_matrix = matrix if self._keep_host else None
+        return idx
+
+    def _result(self):
+        m = DeviceMatrixView(self.index, self.embeddings_matrix) if self._view else self.embeddings_matrix
+        return m, self.emb_id_lookup
+
+    def get_sync(self, db) -> Tuple[Any, np.ndarray]:
+        """src/svs/kb.py:866-877."""
+        if self.index is not None and self.emb_id_lookup is not None:
+            _LOG.info("using cached vectors")
+            return self._result()
+        _LOG.info("re-building cached vectors...")
+        matrix, lookup = self._builder(db)
+        self._install(matrix, lookup)
+        _LOG.info("re-building cached vectors... DONE!")
+        return self._result()
+
+    async def get(self, db) -> Tuple[Any, np.ndarray]:
+        """src/svs/kb.py:879-893 (the build runs on an executor thread)."""
+        if self.index is not None and self.emb_id_lookup is not None:
+            _LOG.info("using cached vectors")
+            return self._result()
+        _LOG.info("re-building cached vectors...")
+        loop = asyncio.get_running_loop()
+        matrix, lookup = await loop.run_in_executor(None, lambda: self._builder(db))
+        await loop.run_in_executor(None, lambda: self._install(matrix, lookup))
+        _LOG.info("re-building cached vectors... DONE!")
+        return self._result()
+
+    # -- the superheavy() body ---------------------------------------------
+    def search(self, query_vec: np.ndarray, n: int) -> List[Tuple[float, int]]:
+        """``superheavy()`` (src/svs/kb.py:1622-1627): [(score, emb_id)]."""
+        idx, lookup = self.hold()
+        try:
+            return [(score, int(lookup[row])) for score, row in idx.search(query_vec, n)]
+        finally:
+            idx.release()
+
+    def hold(self) -> Tuple[Any, np.ndarray]:
+        """(index, lookup) with the caller owning a reference to the index, so a
+        concurrent ``invalidate()`` cannot free it mid-search.  Release it."""
+        with self._mu:
+            idx, lookup = self.index, self.emb_id_lookup
+            if idx is None or lookup is None:
+                raise RuntimeError("embeddings matrix is not loaded (call get_sync/get first)")
+            return idx.share(), lookup
+
+
+# --------------------------------------------------------------------------
+# zero-diff attachment through NumPy's __array_function__ protocol
+# --------------------------------------------------------------------------
+class DeviceScores:
+    """What ``np.dot(DeviceMatrixView, q)`` returns: a lazy length-N score
+    vector.  ``np.argpartition(self, -k)`` runs the device search."""
+
+    ndim = 1
+
+    def __init__(self, index, query_vec: np.ndarray):
+        self._index = index
+        self._q = np.asarray(query_vec, dtype=np.float32)
+        self._found = {}
+        self.shape = (len(index),)
+        self.dtype = np.dtype(np.float32)
+
+    def __len__(self) -> int:
+        return self.shape[0]
+
+    def __getitem__(self, i):
+        i = int(i)
+        if i not in self._found:  # not produced by the last search: fetch the full vector once
+            full = self._index.scores(self._q)
+            self._found = {j: float(v) for j, v in enumerate(full)}
+        return np.float32(self._found[i])
+
+    def __array__(self, dtype=None, copy=None):
+        out = self._index.scores(self._q)
+        return out if dtype is None else out.astype(dtype)
+
+    def __array_function__(self, func, types, args, kwargs):
+        if func is np.argpartition and len(args) >= 2 and args[0] is self and not kwargs:
+            kth = int(args[1])
+            n = self.shape[0]
+            if kth < 0 and -kth <= n:
+                k = -kth
+                res = self._index.search(self._q, k)
+                self._found = {row: score for score, row in res}
+                rows = np.fromiter((row for _, row in res), dtype=np.int64, count=len(res))
+                # argpartition contract: the k largest occupy the last k slots
+                out = np.empty(n, dtype=np.int64) if n == k else None
+                if out is not None:
+                    out[:] = rows[::-1]
+                    return out
+                return _TailOnly(rows[::-1], n)
+        return func(*[np.asarray(a) if isinstance(a, DeviceScores) else a for a in args], **kwargs)
+
+
+class _TailOnly:
+    """Index vector of which only the last k entries are materialised (the only
+    ones ``get_top_k`` reads: ``indices[-top_k:]``, src/svs/util.py:202)."""
+
+    def __init__(self, tail: np.ndarray, n: int):
+        self._tail, self._n = tail, n
+
+    def __getitem__(self, sl):
+        if isinstance(sl, slice) and sl.stop is None and sl.step is None and sl.start is not None \
+                and sl.start < 0 and -sl.start <= len(self._tail):
+            return self._tail[sl.start:]
+        raise IndexError("only the top-k tail of a device argpartition is available")
+
+    def __len__(self) -> int:
+        return self._n
+
+
+class DeviceMatrixView:
+    """Stands in for the numpy ``embeddings_matrix`` inside the reference's
+    ``retrieve()``.  ``.shape`` serves the log line (kb.py:1629); ``np.dot`` with
+    a 1-D query goes to the device; anything else falls back to the host copy
+    (e.g. ``np.dot(M, M.T)`` of document_top_pairwise_scores, kb.py:1651)."""
+
+    def __init__(self, index, host_matrix: Optional[np.ndarray]):
+        self._index = index
+        self._host = host_matrix
+        self.shape = tuple(index.shape)
+        self.ndim = 2
+        self.dtype = np.dtype(np.float32)
+
+    def __len__(self) -> int:
+        return self.shape[0]
+
+    @property
+    def T(self):
+        return self._require_host().T
+
+    def _require_host(self) -> np.ndarray:
+        if self._host is None:
+            raise RuntimeError("host copy of the embeddings matrix was not kept (keep_host_matrix=False)")
+        return self._host
+
+    def __array__(self, dtype=None, copy=None):
+        h = self._require_host()
+        return h if dtype is None else h.astype(dtype)
+
+    def __array_function__(self, func, types, args, kwargs):
+        if func is np.dot and len(args) == 2 and args[0] is self and not kwargs:
+            q = np.asarray(args[1])
+            if q.ndim == 1:
+                if q.shape[0] != self.shape[1] or self.shape[0] == 0:
+                    raise ValueError(f"shapes {self.shape} and {q.shape} not aligned: "
+                                     f"{self.shape[1]} (dim 1) != {q.shape[0]} (dim 0)")
+                return DeviceScores(self._index, q)
+        return func(*[np.asarray(a) if isinstance(a, DeviceMatrixView) else a for a in args], **kwargs)
+
+
+def attach(kb, device: int = 0, keep_host_matrix: bool = True, index_factory: Callable[..., Any] = DeviceIndex):
+    """Swap a reference ``svs.KB`` / ``svs.AsyncKB`` instance's matrix cache for
+    the device-backed one.  No reference source line changes; ``retrieve()``
+    keeps its exact surface."""
+    old = kb.embeddings_matrix
+    new = DeviceEmbeddingsMatrix(device=device, keep_host_matrix=keep_host_matrix,
+                                 index_factory=index_factory, view=True)
+    kb.embeddings_matrix = new
+    try:
+        old.invalidate()
+    except Exception:  # noqa: BLE001
+        pass
+    return kb

@@ -1,0 +1,66 @@
+"""GPU: the reference's retrieve() transcript (tests/golden/kb_cases.json,
+captured from the real svs.KB) replayed on the HIP path through the KB mirror."""
+import asyncio
+
+import numpy as np
+import pytest
+
+from kb_transcript import embedding_func_from, load_cases, replay_async, replay_sync
+
+pytestmark = pytest.mark.gpu
+
+
+def test_sync_kb_transcript_hip(gpu, tmp_path):
+    import svs_amd
+    cases = load_cases()
+    kb = svs_amd.KB(str(tmp_path / "a.sqlite"), embedding_func_from(cases))
+    replay_sync(kb, cases)
+    assert isinstance(kb.embeddings_matrix.index, svs_amd.DeviceIndex)
+    kb.close()
+
+
+def test_async_kb_transcript_hip(gpu, tmp_path):
+    import svs_amd
+    cases = load_cases()
+
+    async def run():
+        kb = svs_amd.AsyncKB(str(tmp_path / "b.sqlite"), embedding_func_from(cases))
+        await replay_async(kb, cases)
+        await kb.close()
+
+    asyncio.run(run())
+
+
+def test_async_concurrent_retrieves_and_invalidate(gpu, tmp_path):
+    """Many retrieve() coroutines at once (superheavy runs on executor threads,
+    outside the lock) with an add in the middle."""
+    import svs_amd
+    rng = np.random.default_rng(0)
+    vecs = rng.standard_normal((400, 64))
+    vecs /= np.linalg.norm(vecs, axis=1, keepdims=True)
+    table = {f"doc {i}": [float(x) for x in vecs[i]] for i in range(400)}
+
+    async def ef(texts):
+        return [table[t] for t in texts]
+
+    async def run():
+        kb = svs_amd.AsyncKB(str(tmp_path / "c.sqlite"), ef)
+        async with kb.bulk_add_docs() as add_doc:
+            for i in range(300):
+                await add_doc(f"doc {i}")
+
+        async def one(i):
+            docs = await kb.retrieve(f"doc {i}", 3)
+            assert docs[0]["doc"]["text"] == f"doc {i}" and abs(docs[0]["score"] - 1.0) < 1e-5
+
+        async def adder():
+            async with kb.bulk_add_docs() as add_doc:
+                for i in range(300, 400):
+                    await add_doc(f"doc {i}")
+
+        await asyncio.gather(*[one(i) for i in range(0, 300, 7)], adder(), *[one(i) for i in range(3, 300, 11)])
+        docs = await kb.retrieve("doc 399", 1)
+        assert docs[0]["doc"]["text"] == "doc 399"
+        await kb.close()
+
+    asyncio.run(run())

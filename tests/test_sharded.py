@@ -1,0 +1,116 @@
+"""Row sharding.  CPU: the gather + host-merge logic with
+world_size-2 gloo processes and a test-double local search; the result must equal
+the unsharded oracle for every G.  GPU: two shards on one card vs one index."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import svs_oracle as oracle
+from synth import corpus_and_query
+
+from svs_amd.sharded import ShardedIndex, merge_topk, shard_bounds
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_shard_bounds_cover_rows_once():
+    for n in (0, 1, 7, 8, 9, 1000, 1_000_000, 100_000_001):
+        for g in (1, 2, 3, 4, 8):
+            spans = [shard_bounds(n, g, r) for r in range(g)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for (a, b), (c, d) in zip(spans, spans[1:]):
+                assert b == c and a <= b and c <= d
+
+
+def test_merge_is_the_total_order():
+    rng = np.random.default_rng(5)
+    v = rng.standard_normal(5000).astype(np.float32)
+    v[rng.choice(5000, 800)] = 0.5          # ties across shards
+    v[10] = 0.0; v[4000] = -0.0
+    k = 300
+    for g in (1, 2, 4, 8):
+        ss, rr = [], []
+        for r in range(g):
+            lo, hi = shard_bounds(5000, g, r)
+            top = oracle.total_order_top_k(v[lo:hi], k)
+            s = np.full(k, -np.inf, np.float32); rw = np.full(k, -1, np.int64)
+            s[:len(top)] = [a for a, _ in top]; rw[:len(top)] = [b + lo for _, b in top]
+            ss.append(s); rr.append(rw)
+        ms, mr = merge_topk(np.stack(ss), np.stack(rr), k)
+        exp = oracle.total_order_top_k(v, k)
+        assert [int(x) for x in mr] == [i for _, i in exp]
+        assert [float(x) for x in ms] == [s for s, _ in exp]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n, d, k, seed, out_q):
+    sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, HERE)
+    import torch.distributed as dist
+    from fake_backend import OracleIndex
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m, qs = corpus_and_query("gaussian", seed, n, d, 3)
+    lo, hi = shard_bounds(n, world, rank)
+    local = OracleIndex(m[lo:hi], row_offset=lo)
+    sh = ShardedIndex(local.search_batch, n_total=n)
+    res = sh.search_batch(qs, k)
+    one = sh.search(qs[0], k)
+    if rank == 0:
+        out_q.put((res[0].tolist(), res[1].tolist(), one))
+    else:
+        assert res is None and one is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,k", [(5003, 100), (64, 100), (3, 5)])
+def test_gloo_world2_matches_unsharded(n, k):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    d, seed = 48, 31
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, d, k, seed, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    scores, rows, one = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    m, qs = corpus_and_query("gaussian", seed, n, d, 3)
+    for qi, qv in enumerate(qs):
+        exp = oracle.total_order_top_k(oracle.cpu_scores(m, qv), k)
+        assert rows[qi] == [i for _, i in exp]
+        assert np.allclose(scores[qi], [s for s, _ in exp], atol=1e-6)
+    assert [i for _, i in one] == rows[0]
+
+
+@pytest.mark.gpu
+def test_two_shards_on_one_gpu_equal_one_index(gpu):
+    """Same kernel, same summation order wherever a row lives: the merged result
+    of any sharding is IDENTICAL (bitwise scores) to the single-index result."""
+    from svs_amd import DeviceIndex
+    n, d, k = 70001, 1536, 100
+    m, qs = corpus_and_query("gaussian", 41, n, d, 4)
+    whole = DeviceIndex(m)
+    for g in (2, 3, 8):
+        shards = []
+        for r in range(g):
+            lo, hi = shard_bounds(n, g, r)
+            shards.append(DeviceIndex(m[lo:hi], row_offset=lo))
+        ws, wr = whole.search_batch(qs, k)
+        parts = [s.search_batch(qs, k) for s in shards]
+        for qi in range(len(qs)):
+            ms, mr = merge_topk(np.stack([p[0][qi] for p in parts]), np.stack([p[1][qi] for p in parts]), k)
+            assert np.array_equal(mr, wr[qi]) and np.array_equal(ms, ws[qi])
+        for s in shards:
+            s.release()
+    whole.release()

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Condenses rocprofv3 outputs (gpurun_out/prof_<tag>_{trace,fetch,write}) into
+profiles/<tag>_*.  FETCH_SIZE on gfx950 reports exactly half the bytes of a wide
+coalesced stream (MI355X_MICROARCH.md, HBM section) -> doubled; unit is KiB.
+WRITE_SIZE is exact (KiB)."""
+import collections, csv, glob, json, os, shutil, sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out")
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+newest = lambda pat: sorted(glob.glob(pat), key=os.path.getmtime)[-1]
+stats = newest(os.path.join(src, f"prof_{tag}_trace", "*", "*_kernel_stats.csv"))
+shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
+kern = {}
+for r in csv.DictReader(open(stats)):
+    if "svs::" in r["Name"]:
+        kern[r["Name"].split("(")[0]] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
+                                          "min_us": float(r["MinNs"]) / 1e3, "max_us": float(r["MaxNs"]) / 1e3,
+                                          "pct": float(r["Percentage"])}
+pmc = collections.defaultdict(dict)
+for name, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    f = newest(os.path.join(src, f"prof_{tag}_{name}", "*", "*_counter_collection.csv"))
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if "svs::" in r["Kernel_Name"] and r["Counter_Name"] == ctr:
+            agg[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+    for k, v in agg.items():
+        pmc[k][ctr + "_KiB_avg"] = sum(v) / len(v)
+        pmc[k]["launches_" + name] = len(v)
+for k, v in pmc.items():
+    rd = 2.0 * v.get("FETCH_SIZE_KiB_avg", 0.0) * 1024   # gfx950 correction: x2
+    wr = v.get("WRITE_SIZE_KiB_avg", 0.0) * 1024
+    v["hbm_read_bytes_per_launch"] = rd
+    v["hbm_write_bytes_per_launch"] = wr
+    v["hbm_bytes_per_launch"] = rd + wr
+out = {"tag": tag, "kernels": kern, "pmc": pmc,
+       "note": "FETCH_SIZE x2 (gfx950 reports half of a wide coalesced read), KiB units; WRITE_SIZE exact"}
+json.dump(out, open(os.path.join(dst, f"{tag}_summary.json"), "w"), indent=1)
+bench = os.path.join(src, f"prof_{tag}_trace.json")
+if os.path.exists(bench):
+    shutil.copy(bench, os.path.join(dst, f"{tag}_bench_line_under_rocprof.json"))
+print(json.dumps(out, indent=1))
