@@ -20,7 +20,7 @@ del m
 torch.cuda.empty_cache()
 qh = q.cpu().numpy()
 bytes_q = n * d * 4
-for variant in (0, 3, 5, 0):
+for variant in (0,):
     idx.set_variant(variant)
     for _ in range(3):
         idx.search(qh, 100)
@@ -36,3 +36,23 @@ for variant in (0, 3, 5, 0):
     idx.set_timing(False)
     print(f"variant {variant}: score {sc/cnt*1e3:8.1f} us  ({bytes_q/(sc/cnt*1e-3)/1e12:5.2f} TB/s)  select {sel/cnt*1e3:7.1f} us  "
           f"p50 latency {np.median(lat)*1e3:7.3f} ms  qps(sync) {iters/wall:8.1f}", flush=True)
+
+# ---- batched throughput (queries per corpus pass)
+g2 = torch.Generator(device=dev); g2.manual_seed(5)
+for variant in (0, 3, 4, 5):
+  idx.set_variant(variant)
+  for nq in (16,):
+    qs = torch.randn((nq, d), device=dev, generator=g2); qs /= qs.norm(dim=1, keepdim=True)
+    qsh = qs.cpu().numpy()
+    for _ in range(2):
+        idx.search_batch(qsh, 100)
+    idx.set_timing(True)
+    t0 = time.perf_counter()
+    reps = 10
+    for _ in range(reps):
+        idx.search_batch(qsh, 100)
+    wall = time.perf_counter() - t0
+    sc, sel, cnt = idx.get_timing()
+    idx.set_timing(False)
+    print(f"variant {variant} batch {nq:3d}: score {sc/cnt*1e3:8.1f} us  select {sel/cnt*1e3:7.1f} us  -> {nq*reps/wall:9.1f} qps "
+          f"(corpus bytes/s per pass {bytes_q*((nq+15)//16)/(sc/cnt*1e-3)/1e12:5.2f} TB/s)", flush=True)
