@@ -45,7 +45,9 @@ typedef enum svs_status {
 /* element type of the HBM-resident corpus (the arithmetic stays f32-accumulate) */
 typedef enum svs_dtype {
   SVS_DTYPE_F32 = 0, /* reference layout: np.zeros((n, m), float32), src/svs/kb.py:600 */
-  SVS_DTYPE_F16 = 1  /* extension for BASELINE.json configs[2]/[3]: rows rounded to f16 on upload */
+  SVS_DTYPE_F16 = 1  /* extension for BASELINE.json configs[2]/[3]: rows AND queries rounded to IEEE
+                        half (RNE), products exact in f32, f32 accumulate.  Parity oracle: numpy's
+                        f32 path on the dequantised corpus and query. */
 } svs_dtype;
 
 typedef struct svs_index_info_t {

@@ -16,7 +16,9 @@
 #include <string>
 #include <vector>
 
+#include "gemm_f16.h"
 #include "gemm_f32.h"
+#include "gemv_f16.h"
 #include "gemv_f32.h"
 #include "select.h"
 
@@ -53,6 +55,7 @@ struct Ctx {
   hipStream_t stream = nullptr;
   float* q_dev = nullptr;       size_t q_cap = 0;        // floats
   float* q16 = nullptr;         size_t q16_cap = 0;      // [16][ld] zero-padded query group
+  _Float16* qh = nullptr;       size_t qh_cap = 0;       // half queries, [rows][ld] zero padded
   float* scores = nullptr;      size_t scores_cap = 0;   // floats
   uint32_t* hist = nullptr;     size_t hist_cap = 0;     // queries
   uint64_t* cand = nullptr;                               // counters live behind hist
@@ -97,6 +100,7 @@ void ctx_destroy(Ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   (void)hipFree(c->q_dev);
   (void)hipFree(c->q16);
+  (void)hipFree(c->qh);
   (void)hipFree(c->scores);
   (void)hipFree(c->hist);
   (void)hipFree(c->cand);
@@ -253,11 +257,61 @@ void launch_generic(const svs_index* idx, const float* q, float* scores, hipStre
                      (const v4f*)idx->rows, q, scores, idx->n, idx->d, idx->ld / 4);
 }
 
+template <int NSTEP>
+void launch_rows_f16(const svs_index* idx, const float* q, float* scores, hipStream_t st) {
+  constexpr int R = NSTEP <= 1 ? 4 : (NSTEP <= 3 ? 2 : 1), WPB = 16;
+  const int64_t rows_per_block = (int64_t)R * WPB;
+  const int64_t blocks = (idx->n + rows_per_block - 1) / rows_per_block;
+  hipLaunchKernelGGL((gemv_f16_oneshot_kernel<NSTEP, R, WPB>), dim3((unsigned)blocks), dim3(WPB * 64), 0, st,
+                     (const u32x4*)idx->rows, (const v4f*)q, scores, idx->n);
+}
+
+template <int T>
+void launch_generic_f16(const svs_index* idx, const _Float16* qh, float* scores, hipStream_t st) {
+  constexpr int RPW = 64 / T;
+  int64_t waves = (idx->n + RPW - 1) / RPW;
+  int blocks = (int)std::min<int64_t>((waves + 3) / 4, (int64_t)idx->cu_count * 8);
+  hipLaunchKernelGGL((gemv_f16_generic_kernel<T>), dim3(blocks), dim3(256), 0, st, (const u32x4*)idx->rows,
+                     (const u32x4*)qh, scores, idx->n, idx->ld / 8);
+}
+
+// rounds nq f32 queries to half into c->qh ([rows_alloc][ld], rows >= nq zero)
+int stage_queries_f16(const svs_index* idx, Ctx* c, const float* q, int nq, int rows_alloc, hipStream_t st) {
+  int rc = grow_dev(&c->qh, &c->qh_cap, (size_t)rows_alloc * idx->ld);
+  if (rc != SVS_OK) return rc;
+  if (rows_alloc > nq) HIP_TRY(hipMemsetAsync(c->qh, 0, (size_t)rows_alloc * idx->ld * sizeof(_Float16), st));
+  hipLaunchKernelGGL(convert_queries_f16_kernel, dim3(std::min(64, nq * 4)), dim3(256), 0, st, q, nq, idx->d, c->qh, idx->ld);
+  return SVS_OK;
+}
+
 // q: device, d floats (unpadded); scores: device, n floats
-int launch_scores(const svs_index* idx, const float* q, float* scores, hipStream_t st) {
-  if (idx->dtype != SVS_DTYPE_F32) return fail(SVS_ERR_UNSUPPORTED, "dtype %d not implemented yet", idx->dtype);
+int launch_scores(const svs_index* idx, Ctx* c, const float* q, float* scores, hipStream_t st) {
   const int variant = idx->variant.load();
   const bool q_aligned = (((uintptr_t)q) & 15) == 0;
+  if (idx->dtype == SVS_DTYPE_F16) {
+    if (idx->ld == idx->d && idx->ld % 512 == 0 && q_aligned) {
+      switch (idx->ld / 512) {
+        case 1: launch_rows_f16<1>(idx, q, scores, st); return SVS_OK;
+        case 2: launch_rows_f16<2>(idx, q, scores, st); return SVS_OK;
+        case 3: launch_rows_f16<3>(idx, q, scores, st); return SVS_OK;
+        case 4: launch_rows_f16<4>(idx, q, scores, st); return SVS_OK;
+        case 6: launch_rows_f16<6>(idx, q, scores, st); return SVS_OK;
+        case 8: launch_rows_f16<8>(idx, q, scores, st); return SVS_OK;
+        default: break;
+      }
+    }
+    int rc = stage_queries_f16(idx, c, q, 1, 1, st);
+    if (rc != SVS_OK) return rc;
+    const int ld8 = idx->ld / 8;
+    if (ld8 <= 1) launch_generic_f16<1>(idx, c->qh, scores, st);
+    else if (ld8 <= 2) launch_generic_f16<2>(idx, c->qh, scores, st);
+    else if (ld8 <= 4) launch_generic_f16<4>(idx, c->qh, scores, st);
+    else if (ld8 <= 8) launch_generic_f16<8>(idx, c->qh, scores, st);
+    else if (ld8 <= 16) launch_generic_f16<16>(idx, c->qh, scores, st);
+    else if (ld8 <= 32) launch_generic_f16<32>(idx, c->qh, scores, st);
+    else launch_generic_f16<64>(idx, c->qh, scores, st);
+    return SVS_OK;
+  }
   if (idx->ld == idx->d && idx->ld % 256 == 0 && q_aligned) {
     switch (idx->ld / 256) {
       case 1: launch_rows<1>(idx, q, scores, st, variant); return SVS_OK;
@@ -318,6 +372,31 @@ int launch_scores_q16(const svs_index* idx, Ctx* c, const float* q_dev, int nq_g
   return SVS_OK;
 }
 
+// ---- 16*NG queries per corpus pass, f16 corpus (gemm_f16.h) -------------------
+int f16_batch_groups(const svs_index* idx) {   // 0: not applicable
+  if (idx->dtype != SVS_DTYPE_F16 || idx->ld % 256 != 0 || idx->variant.load() == 7) return 0;
+  if (idx->ld <= 2304) return 2;
+  if (idx->ld <= 4608) return 1;
+  return 0;
+}
+
+template <int NG>
+int launch_scores_f16_batch(const svs_index* idx, Ctx* c, const float* q_dev, int nq_g, float* scores,
+                            int64_t sstride, hipStream_t st) {
+  int rc = stage_queries_f16(idx, c, q_dev, nq_g, 16 * NG, st);
+  if (rc != SVS_OK) return rc;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute((const void*)gemm_f16_kernel<NG>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
+  });
+  const int rows_per_block = 1024;
+  const unsigned blocks = (unsigned)((idx->n + rows_per_block - 1) / rows_per_block);
+  const size_t lds = (size_t)(idx->ld / 32) * NG * 64 * sizeof(u32x4);
+  hipLaunchKernelGGL((gemm_f16_kernel<NG>), dim3(blocks), dim3(GEMM_WAVES * 64), lds, st, (const _Float16*)idx->rows,
+                     (const _Float16*)c->qh, scores, idx->n, idx->ld, sstride, nq_g, rows_per_block);
+  return SVS_OK;
+}
+
 // ---- whole search on a stream; all pointers are device pointers --------------
 int enqueue_search(svs_index* idx, Ctx* c, const float* q_dev, int nq, int k, int count,
                    float* out_s, int64_t* out_r, hipStream_t st) {
@@ -352,9 +431,17 @@ int enqueue_search(svs_index* idx, Ctx* c, const float* q_dev, int nq, int k, in
                              c->scores + (size_t)q0 * sstride, sstride, st);
       if (rc != SVS_OK) return rc;
     }
+  } else if (nq >= 2 && f16_batch_groups(idx) > 0) {
+    const int ng = f16_batch_groups(idx), per = 16 * ng;
+    for (int q0 = 0; q0 < nq; q0 += per) {
+      const int nq_g = std::min(per, nq - q0);
+      rc = ng == 2 ? launch_scores_f16_batch<2>(idx, c, q_dev + (size_t)q0 * idx->d, nq_g, c->scores + (size_t)q0 * sstride, sstride, st)
+                   : launch_scores_f16_batch<1>(idx, c, q_dev + (size_t)q0 * idx->d, nq_g, c->scores + (size_t)q0 * sstride, sstride, st);
+      if (rc != SVS_OK) return rc;
+    }
   } else {
     for (int qi = 0; qi < nq; ++qi) {
-      rc = launch_scores(idx, q_dev + (size_t)qi * idx->d, c->scores + (size_t)qi * sstride, st);
+      rc = launch_scores(idx, c, q_dev + (size_t)qi * idx->d, c->scores + (size_t)qi * sstride, st);
       if (rc != SVS_OK) return rc;
     }
   }
@@ -416,7 +503,8 @@ int create_common(int64_t n, int32_t d, int32_t store_dtype, int32_t device, int
   if (!out) return fail(SVS_ERR_INVALID, "null out");
   *out = nullptr;
   if (n < 0 || d < 0) return fail(SVS_ERR_INVALID, "negative shape (%lld, %d)", (long long)n, d);
-  if (store_dtype != SVS_DTYPE_F32) return fail(SVS_ERR_UNSUPPORTED, "store dtype %d not implemented yet", store_dtype);
+  if (store_dtype != SVS_DTYPE_F32 && store_dtype != SVS_DTYPE_F16)
+    return fail(SVS_ERR_UNSUPPORTED, "store dtype %d not implemented yet", store_dtype);
   if (n > 0xffffffffll) return fail(SVS_ERR_INVALID, "at most 2^32 rows per handle; shard the corpus");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(SVS_ERR_DEVICE, "no HIP device visible");
@@ -427,12 +515,12 @@ int create_common(int64_t n, int32_t d, int32_t store_dtype, int32_t device, int
   idx->device = device;
   idx->n = n;
   idx->d = d;
-  idx->ld = (d + 3) / 4 * 4;
   idx->dtype = store_dtype;
+  idx->ld = store_dtype == SVS_DTYPE_F16 ? (d + 7) / 8 * 8 : (d + 3) / 4 * 4;  // 16-byte aligned rows
   idx->row_offset = row_offset;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) idx->cu_count = prop.multiProcessorCount;
-  idx->bytes = (size_t)n * (size_t)idx->ld * sizeof(float);
+  idx->bytes = (size_t)n * (size_t)idx->ld * (store_dtype == SVS_DTYPE_F16 ? 2 : 4);
   if (idx->bytes) {
     hipError_t e = hipMalloc(&idx->rows, idx->bytes);
     if (e != hipSuccess) {
@@ -467,36 +555,49 @@ int32_t svs_index_create(const float* host_rows, int64_t n, int32_t d, int32_t s
       index_destroy(idx);
       return fail(SVS_ERR_INVALID, "null host_rows");
     }
-    // pinned double-buffered staging: host memcpy of chunk i+1 overlaps the DMA of chunk i
-    const size_t row_b = (size_t)d * sizeof(float), ld_b = (size_t)idx->ld * sizeof(float);
-    const size_t chunk_rows = std::max<size_t>(1, (32u << 20) / ld_b);
+    // pinned double-buffered staging: host memcpy of chunk i+1 overlaps the DMA of chunk i.
+    // f32 corpus: the DMA writes the padded HBM layout directly (2D copy).
+    // f16 corpus: the DMA lands in a device staging buffer and a kernel rounds it to half.
+    const bool f16 = idx->dtype == SVS_DTYPE_F16;
+    const size_t row_b = (size_t)d * sizeof(float);
+    const size_t chunk_rows = std::max<size_t>(1, (32u << 20) / row_b);
     void* pin[2] = {nullptr, nullptr};
+    float* dstage[2] = {nullptr, nullptr};
     hipEvent_t done[2] = {nullptr, nullptr};
     hipStream_t st = nullptr;
     hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) {
-      e = hipHostMalloc(&pin[i], chunk_rows * ld_b, hipHostMallocDefault);
+      e = hipHostMalloc(&pin[i], chunk_rows * row_b, hipHostMallocDefault);
       if (e == hipSuccess) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
+      if (e == hipSuccess && f16) e = hipMalloc((void**)&dstage[i], chunk_rows * row_b);
     }
+    if (e == hipSuccess && !f16 && idx->ld != d) e = hipMemsetAsync(idx->rows, 0, idx->bytes, st);
     int b = 0;
     for (size_t r0 = 0; r0 < (size_t)n && e == hipSuccess; r0 += chunk_rows, b ^= 1) {
       const size_t rows = std::min(chunk_rows, (size_t)n - r0);
       e = hipEventSynchronize(done[b]);
       if (e != hipSuccess) break;
-      if (idx->ld == d) {
-        memcpy(pin[b], host_rows + r0 * (size_t)d, rows * row_b);
+      memcpy(pin[b], host_rows + r0 * (size_t)d, rows * row_b);
+      if (f16) {
+        e = hipMemcpyAsync(dstage[b], pin[b], rows * row_b, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) {
+          hipLaunchKernelGGL(convert_rows_f16_kernel, dim3(2048), dim3(256), 0, st, (const float*)dstage[b],
+                             (int64_t)rows, d, (int64_t)d, (_Float16*)idx->rows + r0 * (size_t)idx->ld, idx->ld);
+          e = hipGetLastError();
+        }
+      } else if (idx->ld == d) {
+        e = hipMemcpyAsync((float*)idx->rows + r0 * (size_t)d, pin[b], rows * row_b, hipMemcpyHostToDevice, st);
       } else {
-        memset(pin[b], 0, rows * ld_b);
-        for (size_t r = 0; r < rows; ++r)
-          memcpy((char*)pin[b] + r * ld_b, host_rows + (r0 + r) * (size_t)d, row_b);
+        e = hipMemcpy2DAsync((float*)idx->rows + r0 * (size_t)idx->ld, (size_t)idx->ld * sizeof(float), pin[b], row_b,
+                             row_b, rows, hipMemcpyHostToDevice, st);
       }
-      e = hipMemcpyAsync((char*)idx->rows + r0 * ld_b, pin[b], rows * ld_b, hipMemcpyHostToDevice, st);
       if (e == hipSuccess) e = hipEventRecord(done[b], st);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     for (int i = 0; i < 2; ++i) {
       if (done[i]) (void)hipEventDestroy(done[i]);
       if (pin[i]) (void)hipHostFree(pin[i]);
+      if (dstage[i]) (void)hipFree(dstage[i]);
     }
     if (st) (void)hipStreamDestroy(st);
     if (e != hipSuccess) {
@@ -520,10 +621,16 @@ int32_t svs_index_create_from_device(const float* dev_rows, int64_t n, int32_t d
       return fail(SVS_ERR_INVALID, "bad device source (ptr %p, ld %lld)", (const void*)dev_rows, (long long)src_ld);
     }
     hipError_t e = hipSuccess;
-    if (idx->ld != d) e = hipMemset(idx->rows, 0, idx->bytes);
-    if (e == hipSuccess)
-      e = hipMemcpy2D(idx->rows, (size_t)idx->ld * sizeof(float), dev_rows, (size_t)src_ld * sizeof(float),
-                      (size_t)d * sizeof(float), (size_t)n, hipMemcpyDeviceToDevice);
+    if (idx->dtype == SVS_DTYPE_F16) {
+      hipLaunchKernelGGL(convert_rows_f16_kernel, dim3(4096), dim3(256), 0, 0, dev_rows, n, d, src_ld,
+                         (_Float16*)idx->rows, idx->ld);
+      e = hipGetLastError();
+    } else {
+      if (idx->ld != d) e = hipMemset(idx->rows, 0, idx->bytes);
+      if (e == hipSuccess)
+        e = hipMemcpy2D(idx->rows, (size_t)idx->ld * sizeof(float), dev_rows, (size_t)src_ld * sizeof(float),
+                        (size_t)d * sizeof(float), (size_t)n, hipMemcpyDeviceToDevice);
+    }
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
       index_destroy(idx);
@@ -644,7 +751,7 @@ int32_t svs_index_scores(svs_index* idx, const float* query, int32_t d, float* o
   if ((rc = grow_dev(&c->q_dev, &c->q_cap, (size_t)d)) != SVS_OK) return rc;
   if ((rc = grow_dev(&c->scores, &c->scores_cap, (size_t)((idx->n + 3) & ~(int64_t)3))) != SVS_OK) return rc;
   HIP_TRY(hipMemcpyAsync(c->q_dev, query, (size_t)d * sizeof(float), hipMemcpyHostToDevice, c->stream));
-  if ((rc = launch_scores(idx, c->q_dev, c->scores, c->stream)) != SVS_OK) return rc;
+  if ((rc = launch_scores(idx, c, c->q_dev, c->scores, c->stream)) != SVS_OK) return rc;
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(out_scores, c->scores, (size_t)idx->n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));

@@ -17,6 +17,11 @@ import numpy as np
 from . import _native
 
 
+# HBM element type of the corpus.  "f32" is the reference layout; "f16" rounds
+# rows (and queries) to half, f32 accumulate -- BASELINE.json configs[2]/[3].
+_DTYPES = {"f32": _native.DTYPE_F32, "f16": _native.DTYPE_F16}
+
+
 class DeviceIndex:
     """One shard of a corpus, resident in the HBM of one MI355X.
 
@@ -26,7 +31,7 @@ class DeviceIndex:
     """
 
     def __init__(self, matrix: Optional[np.ndarray], device: int = 0, row_offset: int = 0,
-                 *, _handle: Optional[int] = None):
+                 dtype: str = "f32", *, _handle: Optional[int] = None):
         self._lib = _native.load()
         self._lock = threading.Lock()
         self._h: Optional[int] = None
@@ -41,7 +46,7 @@ class DeviceIndex:
                 m = np.ascontiguousarray(m, dtype=np.float32)
             out = C.c_void_p()
             _native.check(self._lib.svs_index_create(
-                m.ctypes.data_as(C.c_void_p), m.shape[0], m.shape[1], _native.DTYPE_F32,
+                m.ctypes.data_as(C.c_void_p), m.shape[0], m.shape[1], _DTYPES[dtype],
                 int(device), int(row_offset), C.byref(out)))
             self._h = out.value
         info = _native.IndexInfo()
@@ -49,10 +54,11 @@ class DeviceIndex:
         self.n, self.d, self.ld = int(info.n), int(info.d), int(info.ld)
         self.device, self.row_offset = int(info.device), int(info.row_offset)
         self.hbm_bytes = int(info.hbm_bytes)
+        self.dtype = {v: k for k, v in _DTYPES.items()}[int(info.dtype)]
 
     @classmethod
     def from_device_pointer(cls, ptr: int, n: int, d: int, src_ld: Optional[int] = None,
-                            device: int = 0, row_offset: int = 0) -> "DeviceIndex":
+                            device: int = 0, row_offset: int = 0, dtype: str = "f32") -> "DeviceIndex":
         """Corpus rows already in device memory (f32): copies them into the
         index's own HBM layout.  ``ptr`` is a raw device address (e.g.
         ``tensor.data_ptr()``)."""
@@ -60,7 +66,7 @@ class DeviceIndex:
         out = C.c_void_p()
         _native.check(lib.svs_index_create_from_device(
             C.c_void_p(ptr), int(n), int(d), int(src_ld if src_ld is not None else d),
-            _native.DTYPE_F32, int(device), int(row_offset), C.byref(out)))
+            _DTYPES[dtype], int(device), int(row_offset), C.byref(out)))
         return cls(None, _handle=out.value)
 
     # -- lifetime ---------------------------------------------------------

@@ -1,0 +1,63 @@
+"""GPU: f16-resident corpus (SVS_DTYPE_F16).  Oracle = numpy's f32 path on the
+dequantised (half-rounded, upcast to f32) corpus and query -- SURVEY.md 8(d)."""
+import numpy as np
+import pytest
+
+from compare import assert_topk_parity
+from oracle import svs_oracle as oracle
+from synth import corpus_and_query
+
+pytestmark = pytest.mark.gpu
+
+
+def _deq(x):
+    return x.astype(np.float16).astype(np.float32)
+
+
+@pytest.mark.parametrize("n,d,k", [(30000, 1536, 100), (9000, 3072, 100), (5000, 512, 10), (7001, 1024, 64),
+                                   (4000, 768, 100), (3000, 100, 7), (600, 3, 5), (50, 1537, 100)])
+def test_f16_single_query(gpu, n, d, k):
+    from svs_amd import DeviceIndex
+    m, qs = corpus_and_query("gaussian", 500 + n, n, d, 3)
+    idx = DeviceIndex(m, dtype="f16")
+    assert idx.dtype == "f16" and idx.hbm_bytes == n * ((d + 7) // 8 * 8) * 2
+    md = _deq(m)
+    for q in qs:
+        qd = _deq(q)
+        got = idx.search(q, k)
+        exp = oracle.cpu_search(md, qd, k)
+        assert_topk_parity([s for s, _ in got], [i for _, i in got], [s for s, _ in exp], [i for _, i in exp],
+                           oracle.cpu_scores_f64(md, qd), label=f"f16 {n}x{d}")
+    sc = idx.scores(qs[0])
+    assert np.max(np.abs(sc - oracle.cpu_scores_f64(md, _deq(qs[0])))) < 5e-7
+    idx.release()
+
+
+@pytest.mark.parametrize("n,d,nq,k", [(20000, 1536, 32, 100), (20000, 1536, 33, 100), (9000, 3072, 20, 50),
+                                      (5000, 768, 7, 100), (12000, 256, 70, 10)])
+def test_f16_batch_mfma(gpu, n, d, nq, k):
+    from svs_amd import DeviceIndex
+    m, qs = corpus_and_query("gaussian", 900 + n + nq, n, d, nq)
+    idx = DeviceIndex(m, dtype="f16")
+    md = _deq(m)
+    bs, br = idx.search_batch(qs, k)
+    for qi, q in enumerate(qs):
+        qd = _deq(q)
+        exp = oracle.cpu_search(md, qd, k)
+        assert_topk_parity(bs[qi], br[qi], [s for s, _ in exp], [i for _, i in exp],
+                           oracle.cpu_scores_f64(md, qd), label=f"f16 batch {n}x{d} q{qi}")
+    idx.release()
+
+
+def test_f16_recall_vs_f32(gpu):
+    """Rounding the corpus to half barely moves the ranking: recall@100 vs the f32 truth."""
+    from svs_amd import DeviceIndex
+    m, qs = corpus_and_query("gaussian", 4242, 50000, 1536, 8)
+    idx = DeviceIndex(m, dtype="f16")
+    rec = []
+    for q in qs:
+        got = {i for _, i in idx.search(q, 100)}
+        exp = {i for _, i in oracle.cpu_search(m, q, 100)}
+        rec.append(len(got & exp) / 100)
+    idx.release()
+    assert min(rec) >= 0.95, rec
