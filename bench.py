@@ -73,7 +73,7 @@ def main():
     import torch
     import torch.distributed as dist
     from svs_amd import DeviceIndex
-    from svs_amd.sharded import merge_topk, shard_bounds
+    from svs_amd.sharded import merge_topk, record_layout, shard_bounds, unpack_records
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -113,8 +113,7 @@ def main():
     queries /= queries.norm(dim=1, keepdim=True)
 
     # per-step output record: [k f32 scores | pad | k i64 rows], gathered as bytes
-    s_bytes = (k * 4 + 7) // 8 * 8
-    rec = s_bytes + k * 8
+    s_bytes, rec = record_layout(k)
     local = torch.zeros((K + W, rec), device=dev, dtype=torch.uint8)
     gathered = torch.zeros((K + W, world, rec), device=dev, dtype=torch.uint8) if world > 1 else None
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.inflight))]
@@ -141,8 +140,7 @@ def main():
         buf = (gathered[i0:i1] if world > 1 else local[i0:i1].unsqueeze(1)).cpu().numpy()
         res = []
         for j in range(i1 - i0):
-            sc = np.ascontiguousarray(buf[j, :, : k * 4]).view(np.float32).reshape(world, k)
-            rw = np.ascontiguousarray(buf[j, :, s_bytes:]).view(np.int64).reshape(world, k)
+            sc, rw = unpack_records(buf[j], world, k)
             res.append(merge_topk(sc, rw, min(k, n_total)) if world > 1 else (sc[0, :count], rw[0, :count]))
         return res
 

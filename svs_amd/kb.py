@@ -158,6 +158,20 @@ class _Store:
         return {"id": row[0], "parent_id": row[1], "level": row[2], "text": row[3],
                 "embedding": row[4] is not None, "meta": json.loads(row[5]) if row[5] is not None else None}
 
+    def fetch_docs_for_embeddings(self, emb_ids: List[int]) -> Dict[int, Dict[str, Any]]:
+        """One ``IN (...)`` query for a whole result list (with
+        the search on the GPU, the reference's 2 SELECTs per result become the
+        bottleneck of ``retrieve()``)."""
+        out: Dict[int, Dict[str, Any]] = {}
+        for c0 in range(0, len(emb_ids), 500):   # stay under SQLITE_MAX_VARIABLE_NUMBER
+            chunk = emb_ids[c0:c0 + 500]
+            marks = ",".join("?" * len(chunk))
+            for row in self.conn.execute(
+                    f"SELECT id, parent_id, level, text, embedding, meta FROM docs WHERE embedding IN ({marks})", chunk):
+                out[row[4]] = {"id": row[0], "parent_id": row[1], "level": row[2], "text": row[3],
+                               "embedding": True, "meta": json.loads(row[5]) if row[5] is not None else None}
+        return out
+
     # -- A7: the producer of the matrix ---------------------------------------
     def build_embeddings_matrix(self) -> Tuple[np.ndarray, np.ndarray]:
         """Same contract as reference src/svs/kb.py:573-618 -- f32 (n, m) C-contiguous
@@ -286,6 +300,28 @@ class KB:
             res = [{"score": score, "doc": self.db.fetch_doc_for_embedding(emb_id)} for score, emb_id in emb_ids]
         _LOG.info(f"retrieved top {n} documents")
         return res
+
+
+    def retrieve_many(self, queries: List[str], n: int) -> List[List[Dict[str, Any]]]:
+        """Batched ``retrieve()``: the queries are embedded
+        in chunks of 200 like bulk_add_docs, searched together (the corpus is read
+        once per 16 queries instead of once per query) and each result list is
+        fetched with one SQL statement.  Element i equals ``retrieve(queries[i], n)``."""
+        _LOG.info(f"retrieving {n} documents for each of {len(queries)} query strings")
+        assert self.db is not None
+        self.embeddings_matrix.get_sync(self.db)
+        vecs: List[List[float]] = []
+        for c0 in range(0, len(queries), BULK_EMBEDDING_CHUNK_SIZE):
+            vecs.extend(self._embed(queries[c0:c0 + BULK_EMBEDDING_CHUNK_SIZE]))
+        if not vecs:
+            return []
+        per_query = self.embeddings_matrix.search_many(np.array(vecs, dtype=np.float32), n)
+        out: List[List[Dict[str, Any]]] = []
+        with self.db.transaction():
+            for emb_ids in per_query:
+                docs = self.db.fetch_docs_for_embeddings([e for _, e in emb_ids])
+                out.append([{"score": s, "doc": docs[e]} for s, e in emb_ids])
+        return out
 
 
 class AsyncKB:

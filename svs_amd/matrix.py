@@ -113,6 +113,16 @@ class DeviceEmbeddingsMatrix:
         finally:
             idx.release()
 
+    def search_many(self, query_vecs: np.ndarray, n: int) -> List[List[Tuple[float, int]]]:
+        """Batched ``superheavy()``: one result list per row of ``query_vecs``;
+        up to 16 (f32) / 32 (f16) queries share one pass over the corpus."""
+        idx, lookup = self.hold()
+        try:
+            scores, rows = idx.search_batch(query_vecs, n)
+            return [[(float(s), int(lookup[r])) for s, r in zip(scores[i], rows[i])] for i in range(len(scores))]
+        finally:
+            idx.release()
+
     def hold(self) -> Tuple[Any, np.ndarray]:
         """(index, lookup) with the caller owning a reference to the index, so a
         concurrent ``invalidate()`` cannot free it mid-search.  Release it."""

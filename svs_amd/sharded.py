@@ -44,6 +44,38 @@ def merge_topk(scores: np.ndarray, rows: np.ndarray, k: int) -> Tuple[np.ndarray
     return scores[order], rows[order]
 
 
+# ---- wire format of one rank's local top-k (one query) -----------------------
+# [k f32 scores | pad to 8 B | k i64 global rows]; entries past the shard's count
+# carry row = -1.  Exchanged as raw bytes so ONE collective moves both arrays.
+def record_layout(k: int) -> Tuple[int, int]:
+    """(offset of the row array, record bytes)."""
+    s_bytes = (k * 4 + 7) // 8 * 8
+    return s_bytes, s_bytes + k * 8
+
+
+def unpack_records(buf: np.ndarray, world: int, k: int) -> Tuple[np.ndarray, np.ndarray]:
+    """``buf``: uint8 (world, record_bytes) -> (scores f32 (world,k), rows i64 (world,k))."""
+    s_bytes, rec = record_layout(k)
+    buf = np.ascontiguousarray(buf, dtype=np.uint8).reshape(world, rec)
+    sc = np.ascontiguousarray(buf[:, : k * 4]).view(np.float32).reshape(world, k)
+    rw = np.ascontiguousarray(buf[:, s_bytes:]).view(np.int64).reshape(world, k)
+    return sc, rw
+
+
+def pack_record(scores: np.ndarray, rows: np.ndarray, k: int) -> np.ndarray:
+    """Host-side packer (tests / CPU paths); the GPU path has the search kernel
+    write both arrays straight into the record."""
+    s_bytes, rec = record_layout(k)
+    out = np.zeros(rec, dtype=np.uint8)
+    sc = np.full(k, -np.inf, dtype=np.float32)
+    rw = np.full(k, -1, dtype=np.int64)
+    sc[: len(scores)] = scores
+    rw[: len(rows)] = rows
+    out[: k * 4] = sc.view(np.uint8)
+    out[s_bytes:] = rw.view(np.uint8)
+    return out
+
+
 class ShardedIndex:
     """Distributed wrapper: ``local_search(queries (nq,d) f32, k) ->
     (scores (nq,c) f32, rows (nq,c) i64 GLOBAL)`` is the per-rank search (a

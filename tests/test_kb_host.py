@@ -38,6 +38,25 @@ def test_async_kb_transcript(tmp_path):
     assert OracleIndex.live == 0
 
 
+def test_retrieve_many_equals_loop_of_retrieve(tmp_path):
+    rng = np.random.default_rng(3)
+    vecs = rng.standard_normal((120, 16)); vecs /= np.linalg.norm(vecs, axis=1, keepdims=True)
+    table = {f"doc {i}": [float(x) for x in vecs[i]] for i in range(120)}
+
+    async def ef(texts):
+        return [table[t] for t in texts]
+
+    kb = svs_amd.KB(str(tmp_path / "many.sqlite"), ef, index_factory=OracleIndex)
+    with kb.bulk_add_docs() as add_doc:
+        for i in range(100):
+            add_doc(f"doc {i}", meta={"i": i})
+    qs = [f"doc {i}" for i in (5, 17, 99, 101, 119)]
+    many = kb.retrieve_many(qs, 7)
+    assert many == [kb.retrieve(q, 7) for q in qs]
+    assert kb.retrieve_many([], 3) == []
+    kb.close()
+
+
 def test_matrix_build_kat(tmp_path):
     """A7: BLOB rows -> (matrix, lookup), non-contiguous ids after a delete
     (reference tests/test_kb.py:753-806)."""

@@ -11,7 +11,8 @@ import pytest
 from oracle import svs_oracle as oracle
 from synth import corpus_and_query
 
-from svs_amd.sharded import ShardedIndex, merge_topk, shard_bounds
+from svs_amd.sharded import (ShardedIndex, merge_topk, pack_record, record_layout, shard_bounds,
+                             unpack_records)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -43,6 +44,79 @@ def test_merge_is_the_total_order():
         exp = oracle.total_order_top_k(v, k)
         assert [int(x) for x in mr] == [i for _, i in exp]
         assert [float(x) for x in ms] == [s for s, _ in exp]
+
+
+def test_record_wire_format_roundtrip():
+    """The byte record bench.py exchanges with one all-gather per query."""
+    rng = np.random.default_rng(2)
+    for k in (1, 3, 100, 101):
+        s_off, rec = record_layout(k)
+        assert s_off % 8 == 0 and rec == s_off + 8 * k
+        world = 4
+        recs, exp_s, exp_r = [], [], []
+        for r in range(world):
+            c = k if r != 2 else max(k - 2, 0)          # one shard holds fewer than k rows
+            sc = np.sort(rng.standard_normal(c).astype(np.float32))[::-1]
+            rw = rng.integers(0, 1 << 40, c)
+            recs.append(pack_record(sc, rw, k)); exp_s.append(sc); exp_r.append(rw)
+        sc, rw = unpack_records(np.stack(recs), world, k)
+        for r in range(world):
+            c = len(exp_s[r])
+            assert np.array_equal(sc[r, :c], exp_s[r]) and np.array_equal(rw[r, :c], exp_r[r])
+            assert np.all(rw[r, c:] == -1) and np.all(np.isneginf(sc[r, c:]))
+        ms, mr = merge_topk(sc, rw, k)
+        assert len(ms) == k and np.all(np.diff(ms) <= 0) and np.all(mr >= 0)
+
+
+def _bench_like_worker(rank, world, port, out_q):
+    """bench.py's exchange, on gloo/CPU tensors: byte records, all_gather_into_tensor
+    with async_op, then unpack + merge on rank 0."""
+    sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, HERE)
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, d, k, steps = 3001, 32, 20, 5
+    m, qs = corpus_and_query("gaussian", 99, n, d, steps)
+    lo, hi = shard_bounds(n, world, rank)
+    _, rec = record_layout(k)
+    local = torch.zeros((steps, rec), dtype=torch.uint8)
+    gathered = torch.zeros((steps, world, rec), dtype=torch.uint8)
+    works = []
+    for i in range(steps):
+        top = oracle.total_order_top_k(oracle.cpu_scores(m[lo:hi], qs[i]), k)
+        local[i] = torch.from_numpy(pack_record(np.array([s for s, _ in top], np.float32),
+                                                np.array([r + lo for _, r in top], np.int64), k))
+        works.append(dist.all_gather_into_tensor(gathered[i].view(-1), local[i], async_op=True))
+    for w in works:
+        w.wait()
+    if rank == 0:
+        res = []
+        for i in range(steps):
+            sc, rw = unpack_records(gathered[i].numpy(), world, k)
+            ms, mr = merge_topk(sc, rw, k)
+            res.append((ms.tolist(), mr.tolist()))
+        out_q.put(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_exchange_on_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_like_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    m, qs = corpus_and_query("gaussian", 99, 3001, 32, 5)
+    for i, (ms, mr) in enumerate(res):
+        exp = oracle.total_order_top_k(oracle.cpu_scores(m, qs[i]), 20)
+        assert mr == [r for _, r in exp]
 
 
 def _free_port():
