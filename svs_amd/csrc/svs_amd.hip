@@ -60,7 +60,6 @@ struct Ctx {
   uint32_t* hist = nullptr;     size_t hist_cap = 0;     // queries
   uint64_t* cand = nullptr;                               // counters live behind hist
   uint64_t* keys = nullptr;     size_t keys_cap = 0;     // u64
-  float* out_s = nullptr;       int64_t* out_r = nullptr; size_t out_cap = 0;  // entries
   float* q_pin = nullptr;       size_t q_pin_cap = 0;
   float* out_s_pin = nullptr;   int64_t* out_r_pin = nullptr; size_t out_pin_cap = 0;
   // Scratch is reused in stream order.  A context stays with the stream that
@@ -105,8 +104,6 @@ void ctx_destroy(Ctx* c) {
   (void)hipFree(c->hist);
   (void)hipFree(c->cand);
   (void)hipFree(c->keys);
-  (void)hipFree(c->out_s);
-  (void)hipFree(c->out_r);
   (void)hipHostFree(c->q_pin);
   (void)hipHostFree(c->out_s_pin);
   (void)hipHostFree(c->out_r_pin);
@@ -188,19 +185,6 @@ int grow_dev(T** p, size_t* cap, size_t need) {
   *cap = 0;
   HIP_TRY(hipMalloc((void**)p, need * sizeof(T)));
   *cap = need;
-  return SVS_OK;
-}
-
-int grow_out(Ctx* c, size_t need) {
-  if (need <= c->out_cap) return SVS_OK;
-  if (c->out_s) HIP_TRY(hipFree(c->out_s));
-  if (c->out_r) HIP_TRY(hipFree(c->out_r));
-  c->out_s = nullptr;
-  c->out_r = nullptr;
-  c->out_cap = 0;
-  HIP_TRY(hipMalloc((void**)&c->out_s, need * sizeof(float)));
-  HIP_TRY(hipMalloc((void**)&c->out_r, need * sizeof(int64_t)));
-  c->out_cap = need;
   return SVS_OK;
 }
 
@@ -681,7 +665,6 @@ int32_t svs_index_search(svs_index* idx, const float* queries, int32_t nq, int32
   struct CtxGuard { svs_index* i; Ctx* c; ~CtxGuard() { ctx_release(i, c); } } cg{idx, c};
   const size_t qn = (size_t)nq * (size_t)d, on = (size_t)nq * (size_t)count;
   if ((rc = grow_dev(&c->q_dev, &c->q_cap, qn)) != SVS_OK) return rc;
-  if ((rc = grow_out(c, on)) != SVS_OK) return rc;
   if (qn > c->q_pin_cap) {
     if (c->q_pin) HIP_TRY(hipHostFree(c->q_pin));
     c->q_pin = nullptr; c->q_pin_cap = 0;
@@ -698,12 +681,12 @@ int32_t svs_index_search(svs_index* idx, const float* queries, int32_t nq, int32
   }
   memcpy(c->q_pin, queries, qn * sizeof(float));
   HIP_TRY(hipMemcpyAsync(c->q_dev, c->q_pin, qn * sizeof(float), hipMemcpyHostToDevice, c->stream));
-  if ((rc = enqueue_search(idx, c, c->q_dev, nq, count, count, c->out_s, c->out_r, c->stream)) != SVS_OK) {
+  // The final top-k kernel stores its k results straight into the pinned host
+  // buffers (device-visible, zero-copy): no D2H copies on the latency path.
+  if ((rc = enqueue_search(idx, c, c->q_dev, nq, count, count, c->out_s_pin, c->out_r_pin, c->stream)) != SVS_OK) {
     (void)hipStreamSynchronize(c->stream);
     return rc;
   }
-  HIP_TRY(hipMemcpyAsync(c->out_s_pin, c->out_s, on * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipMemcpyAsync(c->out_r_pin, c->out_r, on * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   // device layout has stride `count`; the caller's has stride k
   for (int qi = 0; qi < nq; ++qi) {
