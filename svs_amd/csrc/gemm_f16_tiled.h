@@ -1,0 +1,191 @@
+// Batched score stage for an f16 corpus: LDS-tiled MFMA GEMM
+//     S[j][i] = sum_d half(M[i,d]) * half(Q[j,d])   (f32 accumulate)
+// for BASELINE.json configs[2] (1M x 1536 f16, 1024 queries).  The reference's
+// nearest analogue is its np.dot(M, M.T) (src/svs/kb.py:1651); a query batch is
+// by definition a loop of np.dot(M, q) calls (src/svs/kb.py:1623).
+//
+// Roofline: with a BN-query panel per workgroup column the corpus is read
+// ceil(nq/BN) times: HBM-bound for small panels (BN = 32: 8 % MFMA), MFMA-bound
+// from BN = 256 up (AI = 256 flop per corpus byte).
+//
+// Structure (gfx950): workgroup tile = 128 corpus rows x BN queries, BK = 64 halves
+// (exactly ONE 128-byte line per row per k-step), 8 waves.  Both operand tiles
+// are staged HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPRs, every
+// wave instruction moves 8 rows x 128 B of whole lines), double buffered: the
+// DMA of step s+1 is in flight while step s is multiplied.  The LDS image is
+// linear (the DMA writes base + lane*16), so the bank-conflict swizzle is put on
+// the SOURCE address: physical 16-byte chunk c of row r holds global chunk
+// c ^ ((r >> 1) & 7), and fragment reads apply the same XOR -- conflict-free
+// ds_read_b128 for every 16-lane group of v_mfma_f32_16x16x32_f16 operands.
+// Wave tile = TM x TN (64x64 at BN = 256): A and B fragments are read once per
+// k-half and reused across the 4x4 MFMA tiles.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gemm_f32.h"
+#include "gemv_f16.h"
+#include "keys.h"
+
+namespace svs {
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int TG_BM = 128;  // corpus rows per workgroup tile
+constexpr int TG_BK = 64;   // halves per k-step (128 B per row)
+constexpr int TG_WAVES = 8;
+
+__device__ __forceinline__ int tg_swz(int row) { return (row >> 1) & 7; }
+
+// ---- fused top-k epilogue ------------------------------------------------------
+// With B = 1024 queries the score matrix would be 4 GB per batch; instead the
+// epilogue keeps, per query, only candidates that can still be among its k best.
+// The 12 top bits of the orderable score key split ALL floats into 4096 ordered
+// levels (1/8 octave).  level_cnt[L] counts the scores offered at level L; once a
+// level holds k of them nothing below it can be in the top k, so `cut` (monotone,
+// atomicMax) rises to it.  A score is appended to the query's candidate list iff
+// level(score) >= cut.  Exact by construction: a stale (lower) cut only admits
+// extra candidates, and everything at or above the FINAL cut was admitted.  The
+// list is a few thousand keys per query (k ln-ish ramp); select_final_kernel then
+// picks the exact k.  If a list overflows (adversarial row order) the query is
+// flagged and the host re-runs it through the materialised path.
+// Layout matches select.h's per-query scratch: word 0 = n_cand, word 1 = flag.
+constexpr int FUSE_LEVELS = 4096;
+struct FuseState {
+  uint32_t n_cand;
+  uint32_t flag;
+  uint32_t cut;
+  uint32_t pad;
+  uint32_t level_cnt[FUSE_LEVELS];
+};
+
+__device__ __forceinline__ void fuse_offer(FuseState* st, uint64_t* cand, uint32_t cap, uint32_t k,
+                                           float v, uint32_t row, uint32_t cut_hint) {
+  const uint32_t key = score_key(v);
+  const uint32_t level = key >> 20;
+  if (level < cut_hint) return;
+  const uint32_t cut = __hip_atomic_load(&st->cut, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (level < cut) return;
+  const uint32_t seen = atomicAdd(&st->level_cnt[level], 1u) + 1u;
+  if (seen == k && level > cut) atomicMax(&st->cut, level);
+  const uint32_t slot = atomicAdd(&st->n_cand, 1u);
+  if (slot < cap) cand[slot] = ((uint64_t)key << 32) | row;
+}
+
+// Stage `rows` rows x 128 B starting at k-step `s` into `lds` (linear image),
+// rows [row0, row0+rows) of a row-major half matrix with stride ld; rows past
+// row_max are clamped (their products are never stored).  One wave instruction
+// covers 8 rows; the workgroup's waves take instructions round-robin.
+__device__ __forceinline__ void tg_stage(const _Float16* __restrict__ base, int64_t row0, int rows,
+                                         int64_t row_max, int ld, int s, u32x4* lds, int wave, int lane) {
+  const int r_in = lane >> 3, pc = lane & 7;
+  for (int i = wave; i < (rows >> 3); i += TG_WAVES) {
+    const int r = i * 8 + r_in;
+    int64_t gr = row0 + r;
+    gr = gr < row_max ? gr : row_max - 1;
+    const int gc = pc ^ tg_swz(r);
+    const _Float16* src = base + gr * ld + s * TG_BK + gc * 8;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(lds + i * 64), 16, 0, 0);
+  }
+}
+
+// Q: [nq_pad][ld] halves, nq_pad a multiple of BN (rows >= nq zero).
+// FUSE == false: scores [nq][sstride] are written.  FUSE == true: nothing is
+// materialised; fstate [nq] / fcand [nq][fcap] receive the candidates.
+template <int BN, bool FUSE>
+__global__ __launch_bounds__(TG_WAVES * 64) void gemm_f16_tiled_kernel(
+    const _Float16* __restrict__ M, const _Float16* __restrict__ Q, float* __restrict__ scores,
+    int64_t n, int ld, int64_t sstride, int nq, uint32_t* __restrict__ fstate_words, int fstate_stride,
+    uint64_t* __restrict__ fcand, uint32_t fcap, uint32_t fk) {
+  constexpr int TN = BN < 64 ? BN : 64;     // queries per wave tile
+  constexpr int WN = BN / TN;               // waves along the query axis
+  constexpr int WM = TG_WAVES / WN;         // waves along the row axis
+  constexpr int TM = TG_BM / WM;            // rows per wave tile
+  constexpr int MT = TM / 16, NT = TN / 16; // MFMA tiles per wave
+  static_assert(TM % 16 == 0 && TN % 16 == 0, "wave tile must be whole MFMA tiles");
+  extern __shared__ u32x4 tg_lds[];
+  // layout: A buffers [2][128 rows][8 chunks], then B buffers [2][BN rows][8 chunks]
+  auto ldsA = [&](int b) { return tg_lds + b * (TG_BM * 8); };
+  auto ldsB = [&](int b) { return tg_lds + 2 * TG_BM * 8 + b * (BN * 8); };
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int64_t row0 = (int64_t)blockIdx.x * TG_BM;
+  const int q0 = blockIdx.y * BN;
+  const int ksteps = ld / TG_BK;
+
+  f32x4_t acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  tg_stage(M, row0, TG_BM, n, ld, 0, ldsA(0), wave, lane);
+  tg_stage(Q, q0, BN, (int64_t)q0 + BN, ld, 0, ldsB(0), wave, lane);
+  __syncthreads();  // hipcc drains the LDS-DMA (vmcnt(0)) in front of the barrier
+
+  for (int s = 0; s < ksteps; ++s) {
+    const int cur = s & 1;
+    if (s + 1 < ksteps) {
+      tg_stage(M, row0, TG_BM, n, ld, s + 1, ldsA(cur ^ 1), wave, lane);
+      tg_stage(Q, q0, BN, (int64_t)q0 + BN, ld, s + 1, ldsB(cur ^ 1), wave, lane);
+    }
+    const u32x4* A = ldsA(cur);
+    const u32x4* B = ldsB(cur);
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+      h8 fa[MT], fb[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int r = wm * TM + i * 16 + r16;
+        fa[i] = __builtin_bit_cast(h8, A[r * 8 + ((4 * kh + g) ^ tg_swz(r))]);
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int r = wn * TN + j * 16 + r16;
+        fb[j] = __builtin_bit_cast(h8, B[r * 8 + ((4 * kh + g) ^ tg_swz(r))]);
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();  // everyone is done reading `cur`; the DMA into `cur ^ 1` has landed
+  }
+
+  // D layout: column (query) = lane & 15, rows 4 g + r of each 16-row tile
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int query = q0 + wn * TN + j * 16 + r16;
+    if (query < nq) {
+      if constexpr (FUSE) {
+        FuseState* st = (FuseState*)(fstate_words + (int64_t)query * fstate_stride);
+        uint64_t* cq = fcand + (int64_t)query * fcap;
+        const uint32_t hint = st->cut;   // plain load: may be stale (lower), which is safe
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int64_t ob = row0 + wm * TM + i * 16 + 4 * g;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (ob + r < n) fuse_offer(st, cq, fcap, fk, acc[i][j][r], (uint32_t)(ob + r), hint);
+        }
+      } else {
+        float* o = scores + (int64_t)query * sstride;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int64_t ob = row0 + wm * TM + i * 16 + 4 * g;
+          if (ob + 3 < n) *(f32x4_t*)(o + ob) = acc[i][j];
+          else
+            for (int r = 0; r < 4; ++r)
+              if (ob + r < n) o[ob + r] = acc[i][j][r];
+        }
+      }
+    }
+  }
+}
+
+}  // namespace svs

@@ -36,7 +36,7 @@ namespace svs {
 
 constexpr int SEL_KMAX = 2048;    // path A handles k <= SEL_KMAX
 constexpr int SORT_CAP = 4096;    // keys sorted in LDS by one workgroup (32 KiB)
-constexpr int CAND_CAP = 16384;   // survivors of the filter, per query
+constexpr int CAND_CAP = 32768;   // survivors of the filter, per query
 constexpr int WBINS = 4096;       // window histogram bins
 constexpr uint32_t WTOP = 0xC000u;              // key16 of 2.0f
 constexpr uint32_t WBASE = WTOP - (WBINS - 1);  // key16 of ~2^-31
@@ -304,7 +304,10 @@ __device__ __forceinline__ uint64_t block_radix_select(KeyAt key_at, int64_t M, 
 }
 
 // ---- path A launch 3 / path D.  grid = nq, one workgroup per query ------------
-// mode 0: path A (candidates from the filter); mode 1: path D (n <= SORT_CAP).
+// mode 0: path A (candidates from the filter); mode 1: path D (n <= SORT_CAP);
+// mode 3: candidates from the fused GEMM epilogue (no score vector exists): an
+// overflowed list cannot be repaired here, so the query is marked for the host
+// (out_rows[0] = -2) and re-run through the materialised path.
 __global__ __launch_bounds__(FINAL_THREADS) void select_final_kernel(
     const float* __restrict__ scores, int64_t n, int64_t score_stride, int k_out, int count,
     int mode, uint32_t* __restrict__ scratch, const uint64_t* __restrict__ cand,
@@ -326,6 +329,16 @@ __global__ __launch_bounds__(FINAL_THREADS) void select_final_kernel(
     const uint64_t* cq = cand + (int64_t)qi * CAND_CAP;
     const uint32_t flag = hdr->flag;
     const uint32_t n_cand = hdr->n_cand;
+    if (mode == 3 && (n_cand > (uint32_t)CAND_CAP || n_cand < (uint32_t)count)) {
+      __syncthreads();
+      uint32_t* w0 = scratch + (int64_t)qi * SCR_WORDS;
+      for (int i = threadIdx.x; i < SCR_WORDS; i += blockDim.x) w0[i] = 0;
+      for (int i = threadIdx.x; i < k_out; i += blockDim.x) {
+        os[i] = -__builtin_inff();
+        orow[i] = -2;
+      }
+      return;
+    }
     if (flag == 0 && n_cand <= (uint32_t)SORT_CAP) {
       m = next_pow2((int)n_cand < 2 ? 2 : (int)n_cand);
       for (int i = threadIdx.x; i < m; i += blockDim.x) S[i] = i < (int)n_cand ? cq[i] : 0ull;

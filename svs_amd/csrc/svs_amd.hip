@@ -16,7 +16,7 @@
 #include <string>
 #include <vector>
 
-#include "gemm_f16.h"
+#include "gemm_f16_tiled.h"
 #include "gemm_f32.h"
 #include "gemv_f16.h"
 #include "gemv_f32.h"
@@ -356,39 +356,60 @@ int launch_scores_q16(const svs_index* idx, Ctx* c, const float* q_dev, int nq_g
   return SVS_OK;
 }
 
-// ---- 16*NG queries per corpus pass, f16 corpus (gemm_f16.h) -------------------
-int f16_batch_groups(const svs_index* idx) {   // 0: not applicable
-  if (idx->dtype != SVS_DTYPE_F16 || idx->ld % 256 != 0 || idx->variant.load() == 7) return 0;
-  if (idx->ld <= 2304) return 2;
-  if (idx->ld <= 4608) return 1;
-  return 0;
+// ---- LDS-tiled MFMA GEMM, f16 corpus (gemm_f16_tiled.h) -----------------------
+bool f16_tiled_ok(const svs_index* idx) {
+  const int v = idx->variant.load();
+  return idx->dtype == SVS_DTYPE_F16 && idx->ld % TG_BK == 0 && v != 7;
 }
 
-template <int NG>
-int launch_scores_f16_batch(const svs_index* idx, Ctx* c, const float* q_dev, int nq_g, float* scores,
-                            int64_t sstride, hipStream_t st) {
-  int rc = stage_queries_f16(idx, c, q_dev, nq_g, 16 * NG, st);
-  if (rc != SVS_OK) return rc;
+struct FuseLaunch {   // non-null state: fused top-k epilogue, no score matrix
+  uint32_t* state = nullptr;
+  uint64_t* cand = nullptr;
+  uint32_t k = 0;
+};
+
+template <int BN, bool FUSE>
+int launch_f16_tiled_bn(const svs_index* idx, Ctx* c, int nq, float* scores, int64_t sstride, FuseLaunch fl,
+                        hipStream_t st) {
   static std::once_flag once;
+  const size_t lds = (size_t)(2 * TG_BM * 8 + 2 * BN * 8) * sizeof(u32x4);
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute((const void*)gemm_f16_kernel<NG>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
+    (void)hipFuncSetAttribute((const void*)gemm_f16_tiled_kernel<BN, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)((2 * TG_BM * 8 + 2 * BN * 8) * sizeof(u32x4)));
   });
-  const int rows_per_block = 1024;
-  const unsigned blocks = (unsigned)((idx->n + rows_per_block - 1) / rows_per_block);
-  const size_t lds = (size_t)(idx->ld / 32) * NG * 64 * sizeof(u32x4);
-  hipLaunchKernelGGL((gemm_f16_kernel<NG>), dim3(blocks), dim3(GEMM_WAVES * 64), lds, st, (const _Float16*)idx->rows,
-                     (const _Float16*)c->qh, scores, idx->n, idx->ld, sstride, nq_g, rows_per_block);
+  const unsigned gx = (unsigned)((idx->n + TG_BM - 1) / TG_BM), gy = (unsigned)((nq + BN - 1) / BN);
+  hipLaunchKernelGGL((gemm_f16_tiled_kernel<BN, FUSE>), dim3(gx, gy), dim3(TG_WAVES * 64), lds, st,
+                     (const _Float16*)idx->rows, (const _Float16*)c->qh, scores, idx->n, idx->ld, sstride, nq,
+                     fl.state, (int)SCR_WORDS, fl.cand, (uint32_t)CAND_CAP, fl.k);
   return SVS_OK;
+}
+
+int launch_scores_f16_tiled(const svs_index* idx, Ctx* c, const float* q_dev, int nq, float* scores,
+                            int64_t sstride, FuseLaunch fl, hipStream_t st) {
+  const int bn = nq <= 32 ? 32 : (nq <= 64 ? 64 : (nq <= 128 ? 128 : 256));
+  const int nq_pad = (nq + bn - 1) / bn * bn;
+  int rc = stage_queries_f16(idx, c, q_dev, nq, nq_pad, st);
+  if (rc != SVS_OK) return rc;
+  const bool f = fl.state != nullptr;
+  switch (bn) {
+    case 32: return f ? launch_f16_tiled_bn<32, true>(idx, c, nq, scores, sstride, fl, st) : launch_f16_tiled_bn<32, false>(idx, c, nq, scores, sstride, fl, st);
+    case 64: return f ? launch_f16_tiled_bn<64, true>(idx, c, nq, scores, sstride, fl, st) : launch_f16_tiled_bn<64, false>(idx, c, nq, scores, sstride, fl, st);
+    case 128: return f ? launch_f16_tiled_bn<128, true>(idx, c, nq, scores, sstride, fl, st) : launch_f16_tiled_bn<128, false>(idx, c, nq, scores, sstride, fl, st);
+    default: return f ? launch_f16_tiled_bn<256, true>(idx, c, nq, scores, sstride, fl, st) : launch_f16_tiled_bn<256, false>(idx, c, nq, scores, sstride, fl, st);
+  }
 }
 
 // ---- whole search on a stream; all pointers are device pointers --------------
 int enqueue_search(svs_index* idx, Ctx* c, const float* q_dev, int nq, int k, int count,
-                   float* out_s, int64_t* out_r, hipStream_t st) {
+                   float* out_s, int64_t* out_r, hipStream_t st, bool allow_fused = false) {
   const int64_t n = idx->n;
   const int64_t sstride = (n + 3) & ~(int64_t)3;  // float4-aligned score vectors
   int rc;
-  if ((rc = grow_dev(&c->scores, &c->scores_cap, (size_t)nq * (size_t)sstride)) != SVS_OK) return rc;
   const bool path_a = k > 0 && n > SORT_CAP && count <= SEL_KMAX;
+  // Fused top-k epilogue (no score matrix): batched f16 GEMM only; a query whose
+  // candidate list overflows comes back marked and is re-run by the caller.
+  const bool fused = allow_fused && path_a && nq >= 64 && f16_tiled_ok(idx) && idx->variant.load() != 6;
+  if (!fused && (rc = grow_dev(&c->scores, &c->scores_cap, (size_t)nq * (size_t)sstride)) != SVS_OK) return rc;
   if (path_a && (size_t)nq > c->hist_cap) {
     if (c->hist) HIP_TRY(hipFree(c->hist));
     if (c->cand) HIP_TRY(hipFree(c->cand));
@@ -415,14 +436,11 @@ int enqueue_search(svs_index* idx, Ctx* c, const float* q_dev, int nq, int k, in
                              c->scores + (size_t)q0 * sstride, sstride, st);
       if (rc != SVS_OK) return rc;
     }
-  } else if (nq >= 2 && f16_batch_groups(idx) > 0) {
-    const int ng = f16_batch_groups(idx), per = 16 * ng;
-    for (int q0 = 0; q0 < nq; q0 += per) {
-      const int nq_g = std::min(per, nq - q0);
-      rc = ng == 2 ? launch_scores_f16_batch<2>(idx, c, q_dev + (size_t)q0 * idx->d, nq_g, c->scores + (size_t)q0 * sstride, sstride, st)
-                   : launch_scores_f16_batch<1>(idx, c, q_dev + (size_t)q0 * idx->d, nq_g, c->scores + (size_t)q0 * sstride, sstride, st);
-      if (rc != SVS_OK) return rc;
-    }
+  } else if (nq >= 2 && f16_tiled_ok(idx)) {
+    FuseLaunch fl;
+    if (fused) fl = FuseLaunch{c->hist, c->cand, (uint32_t)count};
+    rc = launch_scores_f16_tiled(idx, c, q_dev, nq, fused ? nullptr : c->scores, sstride, fl, st);
+    if (rc != SVS_OK) return rc;
   } else {
     for (int qi = 0; qi < nq; ++qi) {
       rc = launch_scores(idx, c, q_dev + (size_t)qi * idx->d, c->scores + (size_t)qi * sstride, st);
@@ -435,6 +453,9 @@ int enqueue_search(svs_index* idx, Ctx* c, const float* q_dev, int nq, int k, in
     if (n <= SORT_CAP) {
       hipLaunchKernelGGL(select_final_kernel, dim3(nq), dim3(FINAL_THREADS), 0, st, c->scores, n, sstride, k,
                          count, 1, (uint32_t*)nullptr, (const uint64_t*)nullptr, idx->row_offset, out_s, out_r);
+    } else if (fused) {
+      hipLaunchKernelGGL(select_final_kernel, dim3(nq), dim3(FINAL_THREADS), 0, st, (const float*)nullptr, n, sstride, k, count, 3,
+                         c->hist, c->cand, idx->row_offset, out_s, out_r);
     } else if (path_a) {
       const int64_t per_block = (int64_t)FA_THREADS * SEL_VPT * 4;
       const unsigned blocks = (unsigned)((n + per_block - 1) / per_block);
@@ -683,11 +704,21 @@ int32_t svs_index_search(svs_index* idx, const float* queries, int32_t nq, int32
   HIP_TRY(hipMemcpyAsync(c->q_dev, c->q_pin, qn * sizeof(float), hipMemcpyHostToDevice, c->stream));
   // The final top-k kernel stores its k results straight into the pinned host
   // buffers (device-visible, zero-copy): no D2H copies on the latency path.
-  if ((rc = enqueue_search(idx, c, c->q_dev, nq, count, count, c->out_s_pin, c->out_r_pin, c->stream)) != SVS_OK) {
+  if ((rc = enqueue_search(idx, c, c->q_dev, nq, count, count, c->out_s_pin, c->out_r_pin, c->stream, true)) != SVS_OK) {
     (void)hipStreamSynchronize(c->stream);
     return rc;
   }
   HIP_TRY(hipStreamSynchronize(c->stream));
+  // queries whose fused candidate list overflowed (marked row -2): exact re-run, one by one
+  for (int qi = 0; qi < nq; ++qi) {
+    if (c->out_r_pin[(size_t)qi * count] != -2) continue;
+    if ((rc = enqueue_search(idx, c, c->q_dev + (size_t)qi * d, 1, count, count, c->out_s_pin + (size_t)qi * count,
+                             c->out_r_pin + (size_t)qi * count, c->stream, false)) != SVS_OK) {
+      (void)hipStreamSynchronize(c->stream);
+      return rc;
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
   // device layout has stride `count`; the caller's has stride k
   for (int qi = 0; qi < nq; ++qi) {
     memcpy(out_scores + (size_t)qi * k, c->out_s_pin + (size_t)qi * count, (size_t)count * sizeof(float));

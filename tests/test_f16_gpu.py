@@ -61,3 +61,49 @@ def test_f16_recall_vs_f32(gpu):
         rec.append(len(got & exp) / 100)
     idx.release()
     assert min(rec) >= 0.95, rec
+
+
+@pytest.mark.parametrize("n,d,nq,k", [(40000, 1536, 64, 100), (25000, 768, 100, 10), (20000, 512, 300, 100)])
+def test_f16_large_batch_fused_topk(gpu, n, d, nq, k):
+    """nq >= 64 takes the tiled MFMA GEMM with the fused top-k epilogue (the score
+    matrix is never materialised)."""
+    from svs_amd import DeviceIndex
+    m, qs = corpus_and_query("gaussian", 7000 + n, n, d, nq)
+    idx = DeviceIndex(m, dtype="f16")
+    md = _deq(m)
+    bs, br = idx.search_batch(qs, k)
+    for qi in range(0, nq, max(1, nq // 16)):
+        qd = _deq(qs[qi])
+        exp = oracle.cpu_search(md, qd, k)
+        assert_topk_parity(bs[qi], br[qi], [s for s, _ in exp], [i for _, i in exp],
+                           oracle.cpu_scores_f64(md, qd), label=f"f16 fused {n}x{d} q{qi}")
+    # same results as the materialised path (queries one at a time), up to near ties
+    for qi in (0, nq - 1):
+        one = idx.search(qs[qi], k)
+        assert np.max(np.abs(np.array([s for s, _ in one]) - bs[qi])) < 2e-6
+    idx.release()
+
+
+def test_f16_fused_overflow_falls_back_exactly(gpu):
+    """Adversarial row order: scores rise with the row index, so every row passes
+    the streaming cut and the candidate lists overflow; those queries must be
+    re-run through the materialised path and still be exact."""
+    from svs_amd import DeviceIndex
+    rng = np.random.default_rng(11)
+    n, d, nq, k = 120000, 64, 70, 50
+    u = rng.standard_normal(d); u /= np.linalg.norm(u)
+    v = rng.standard_normal((n, d)); v -= np.outer(v @ u, u); v /= np.linalg.norm(v, axis=1, keepdims=True)
+    c = np.linspace(0.05, 0.95, n)[:, None]                 # cosine to u grows with the row
+    m = (c * u[None, :] + np.sqrt(1 - c * c) * v).astype(np.float32)
+    qs = rng.standard_normal((nq, d)); qs /= np.linalg.norm(qs, axis=1, keepdims=True)
+    qs[:8] = u                                              # 8 adversarial queries
+    qs = qs.astype(np.float32)
+    idx = DeviceIndex(m, dtype="f16")
+    md = _deq(m)
+    bs, br = idx.search_batch(qs, k)
+    for qi in list(range(10)) + [nq - 1]:
+        qd = _deq(qs[qi])
+        exp = oracle.cpu_search(md, qd, k)
+        assert_topk_parity(bs[qi], br[qi], [s for s, _ in exp], [i for _, i in exp],
+                           oracle.cpu_scores_f64(md, qd), label=f"overflow q{qi}")
+    idx.release()
