@@ -39,37 +39,23 @@ __device__ __forceinline__ int tg_swz(int row) { return (row >> 1) & 7; }
 
 // ---- fused top-k epilogue ------------------------------------------------------
 // With B = 1024 queries the score matrix would be 4 GB per batch; instead the
-// epilogue keeps, per query, only candidates that can still be among its k best.
-// The 12 top bits of the orderable score key split ALL floats into 4096 ordered
-// levels (1/8 octave).  level_cnt[L] counts the scores offered at level L; once a
-// level holds k of them nothing below it can be in the top k, so `cut` (monotone,
-// atomicMax) rises to it.  A score is appended to the query's candidate list iff
-// level(score) >= cut.  Exact by construction: a stale (lower) cut only admits
-// extra candidates, and everything at or above the FINAL cut was admitted.  The
-// list is a few thousand keys per query (k ln-ish ramp); select_final_kernel then
-// picks the exact k.  If a list overflows (adversarial row order) the query is
-// flagged and the host re-runs it through the materialised path.
-// Layout matches select.h's per-query scratch: word 0 = n_cand, word 1 = flag.
-constexpr int FUSE_LEVELS = 4096;
-struct FuseState {
-  uint32_t n_cand;
-  uint32_t flag;
-  uint32_t cut;
-  uint32_t pad;
-  uint32_t level_cnt[FUSE_LEVELS];
-};
-
-__device__ __forceinline__ void fuse_offer(FuseState* st, uint64_t* cand, uint32_t cap, uint32_t k,
-                                           float v, uint32_t row, uint32_t cut_hint) {
-  const uint32_t key = score_key(v);
-  const uint32_t level = key >> 20;
-  if (level < cut_hint) return;
-  const uint32_t cut = __hip_atomic_load(&st->cut, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (level < cut) return;
-  const uint32_t seen = atomicAdd(&st->level_cnt[level], 1u) + 1u;
-  if (seen == k && level > cut) atomicMax(&st->cut, level);
-  const uint32_t slot = atomicAdd(&st->n_cand, 1u);
-  if (slot < cap) cand[slot] = ((uint64_t)key << 32) | row;
+// epilogue keeps, per query, only the scores that reach a threshold thr[q] known
+// BEFORE the pass: the exact k-th best score of the first `prefix` corpus rows
+// (a small materialised GEMM + the ordinary top-k stage).  The k-th best of any
+// subset is a lower bound of the global k-th best, so every global winner passes
+// (score >= thr[q]) and the result is exact; about k*n/prefix candidates per
+// query survive (6k at 1M rows, prefix 16k, k = 100).  select_final_kernel then
+// picks the exact k.  If a list overflows (rows ordered by similarity to the
+// query) the query is marked and the host re-runs it through the materialised
+// path.  (A streaming variant that learned the threshold during the pass, level
+// counters + monotone cut, was exact too but flooded the atomics while hundreds
+// of workgroups still saw the initial cut: 10.7 ms vs 7.0 ms unfused.)
+// Layout of the per-query header matches select.h: word 0 = n_cand, word 1 = flag.
+__device__ __forceinline__ void fuse_offer(uint32_t* hdr, uint64_t* cand, uint32_t cap, float thr, float v,
+                                           uint32_t row) {
+  if (!(v >= thr)) return;
+  const uint32_t slot = atomicAdd(hdr, 1u);
+  if (slot < cap) cand[slot] = ((uint64_t)score_key(v) << 32) | row;
 }
 
 // Stage `rows` rows x 128 B starting at k-step `s` into `lds` (linear image),
@@ -92,12 +78,13 @@ __device__ __forceinline__ void tg_stage(const _Float16* __restrict__ base, int6
 
 // Q: [nq_pad][ld] halves, nq_pad a multiple of BN (rows >= nq zero).
 // FUSE == false: scores [nq][sstride] are written.  FUSE == true: nothing is
-// materialised; fstate [nq] / fcand [nq][fcap] receive the candidates.
+// materialised; scores >= fthr[q * fthr_stride] go to fcand [nq][fcap], counted in
+// the per-query header word fstate_words[q * fstate_stride].
 template <int BN, bool FUSE>
 __global__ __launch_bounds__(TG_WAVES * 64) void gemm_f16_tiled_kernel(
     const _Float16* __restrict__ M, const _Float16* __restrict__ Q, float* __restrict__ scores,
     int64_t n, int ld, int64_t sstride, int nq, uint32_t* __restrict__ fstate_words, int fstate_stride,
-    uint64_t* __restrict__ fcand, uint32_t fcap, uint32_t fk) {
+    uint64_t* __restrict__ fcand, uint32_t fcap, const float* __restrict__ fthr, int fthr_stride) {
   constexpr int TN = BN < 64 ? BN : 64;     // queries per wave tile
   constexpr int WN = BN / TN;               // waves along the query axis
   constexpr int WM = TG_WAVES / WN;         // waves along the row axis
@@ -163,15 +150,15 @@ __global__ __launch_bounds__(TG_WAVES * 64) void gemm_f16_tiled_kernel(
     const int query = q0 + wn * TN + j * 16 + r16;
     if (query < nq) {
       if constexpr (FUSE) {
-        FuseState* st = (FuseState*)(fstate_words + (int64_t)query * fstate_stride);
+        uint32_t* hdr = fstate_words + (int64_t)query * fstate_stride;
         uint64_t* cq = fcand + (int64_t)query * fcap;
-        const uint32_t hint = st->cut;   // plain load: may be stale (lower), which is safe
+        const float thr = fthr[(int64_t)query * fthr_stride];
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
           const int64_t ob = row0 + wm * TM + i * 16 + 4 * g;
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (ob + r < n) fuse_offer(st, cq, fcap, fk, acc[i][j][r], (uint32_t)(ob + r), hint);
+            if (ob + r < n) fuse_offer(hdr, cq, fcap, thr, acc[i][j][r], (uint32_t)(ob + r));
         }
       } else {
         float* o = scores + (int64_t)query * sstride;

@@ -56,6 +56,8 @@ struct Ctx {
   float* q_dev = nullptr;       size_t q_cap = 0;        // floats
   float* q16 = nullptr;         size_t q16_cap = 0;      // [16][ld] zero-padded query group
   _Float16* qh = nullptr;       size_t qh_cap = 0;       // half queries, [rows][ld] zero padded
+  float* pref_s = nullptr;      size_t pref_s_cap = 0;   // fused GEMM: top-k of the prefix rows (thresholds)
+  int64_t* pref_r = nullptr;    size_t pref_r_cap = 0;
   float* scores = nullptr;      size_t scores_cap = 0;   // floats
   uint32_t* hist = nullptr;     size_t hist_cap = 0;     // queries
   uint64_t* cand = nullptr;                               // counters live behind hist
@@ -100,6 +102,8 @@ void ctx_destroy(Ctx* c) {
   (void)hipFree(c->q_dev);
   (void)hipFree(c->q16);
   (void)hipFree(c->qh);
+  (void)hipFree(c->pref_s);
+  (void)hipFree(c->pref_r);
   (void)hipFree(c->scores);
   (void)hipFree(c->hist);
   (void)hipFree(c->cand);
@@ -365,51 +369,96 @@ bool f16_tiled_ok(const svs_index* idx) {
 struct FuseLaunch {   // non-null state: fused top-k epilogue, no score matrix
   uint32_t* state = nullptr;
   uint64_t* cand = nullptr;
-  uint32_t k = 0;
+  const float* thr = nullptr;   // thr[q * thr_stride]: lower bound of query q's k-th best score
+  int thr_stride = 0;
 };
 
 template <int BN, bool FUSE>
-int launch_f16_tiled_bn(const svs_index* idx, Ctx* c, int nq, float* scores, int64_t sstride, FuseLaunch fl,
-                        hipStream_t st) {
+int launch_f16_tiled_bn(const svs_index* idx, Ctx* c, int64_t n_rows, int nq, float* scores, int64_t sstride,
+                        FuseLaunch fl, hipStream_t st) {
   static std::once_flag once;
   const size_t lds = (size_t)(2 * TG_BM * 8 + 2 * BN * 8) * sizeof(u32x4);
   std::call_once(once, [] {
     (void)hipFuncSetAttribute((const void*)gemm_f16_tiled_kernel<BN, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)((2 * TG_BM * 8 + 2 * BN * 8) * sizeof(u32x4)));
   });
-  const unsigned gx = (unsigned)((idx->n + TG_BM - 1) / TG_BM), gy = (unsigned)((nq + BN - 1) / BN);
+  const unsigned gx = (unsigned)((n_rows + TG_BM - 1) / TG_BM), gy = (unsigned)((nq + BN - 1) / BN);
   hipLaunchKernelGGL((gemm_f16_tiled_kernel<BN, FUSE>), dim3(gx, gy), dim3(TG_WAVES * 64), lds, st,
-                     (const _Float16*)idx->rows, (const _Float16*)c->qh, scores, idx->n, idx->ld, sstride, nq,
-                     fl.state, (int)SCR_WORDS, fl.cand, (uint32_t)CAND_CAP, fl.k);
+                     (const _Float16*)idx->rows, (const _Float16*)c->qh, scores, n_rows, idx->ld, sstride, nq,
+                     fl.state, (int)SCR_WORDS, fl.cand, (uint32_t)CAND_CAP, fl.thr, fl.thr_stride);
   return SVS_OK;
 }
 
-int launch_scores_f16_tiled(const svs_index* idx, Ctx* c, const float* q_dev, int nq, float* scores,
-                            int64_t sstride, FuseLaunch fl, hipStream_t st) {
+// rows [0, n_rows) of the corpus; restage == false reuses the half queries already in c->qh
+int launch_scores_f16_tiled(const svs_index* idx, Ctx* c, const float* q_dev, int64_t n_rows, int nq, float* scores,
+                            int64_t sstride, FuseLaunch fl, hipStream_t st, bool restage = true) {
   const int bn = nq <= 32 ? 32 : (nq <= 64 ? 64 : (nq <= 128 ? 128 : 256));
   const int nq_pad = (nq + bn - 1) / bn * bn;
-  int rc = stage_queries_f16(idx, c, q_dev, nq, nq_pad, st);
-  if (rc != SVS_OK) return rc;
+  if (restage) {
+    int rc = stage_queries_f16(idx, c, q_dev, nq, nq_pad, st);
+    if (rc != SVS_OK) return rc;
+  }
   const bool f = fl.state != nullptr;
   switch (bn) {
-    case 32: return f ? launch_f16_tiled_bn<32, true>(idx, c, nq, scores, sstride, fl, st) : launch_f16_tiled_bn<32, false>(idx, c, nq, scores, sstride, fl, st);
-    case 64: return f ? launch_f16_tiled_bn<64, true>(idx, c, nq, scores, sstride, fl, st) : launch_f16_tiled_bn<64, false>(idx, c, nq, scores, sstride, fl, st);
-    case 128: return f ? launch_f16_tiled_bn<128, true>(idx, c, nq, scores, sstride, fl, st) : launch_f16_tiled_bn<128, false>(idx, c, nq, scores, sstride, fl, st);
-    default: return f ? launch_f16_tiled_bn<256, true>(idx, c, nq, scores, sstride, fl, st) : launch_f16_tiled_bn<256, false>(idx, c, nq, scores, sstride, fl, st);
+    case 32: return f ? launch_f16_tiled_bn<32, true>(idx, c, n_rows, nq, scores, sstride, fl, st) : launch_f16_tiled_bn<32, false>(idx, c, n_rows, nq, scores, sstride, fl, st);
+    case 64: return f ? launch_f16_tiled_bn<64, true>(idx, c, n_rows, nq, scores, sstride, fl, st) : launch_f16_tiled_bn<64, false>(idx, c, n_rows, nq, scores, sstride, fl, st);
+    case 128: return f ? launch_f16_tiled_bn<128, true>(idx, c, n_rows, nq, scores, sstride, fl, st) : launch_f16_tiled_bn<128, false>(idx, c, n_rows, nq, scores, sstride, fl, st);
+    default: return f ? launch_f16_tiled_bn<256, true>(idx, c, n_rows, nq, scores, sstride, fl, st) : launch_f16_tiled_bn<256, false>(idx, c, n_rows, nq, scores, sstride, fl, st);
   }
 }
 
 // ---- whole search on a stream; all pointers are device pointers --------------
+// Top-k stage over a materialised score matrix scores[nq][sstride] with n_eff rows.
+int run_select(svs_index* idx, Ctx* c, const float* scores, int64_t n_eff, int64_t sstride, int nq, int k,
+               int count, float* out_s, int64_t* out_r, hipStream_t st) {
+  int rc;
+  if (n_eff <= SORT_CAP) {
+    hipLaunchKernelGGL(select_final_kernel, dim3(nq), dim3(FINAL_THREADS), 0, st, scores, n_eff, sstride, k, count, 1,
+                       (uint32_t*)nullptr, (const uint64_t*)nullptr, idx->row_offset, out_s, out_r);
+  } else if (count <= SEL_KMAX) {
+    const int64_t per_block = (int64_t)FA_THREADS * SEL_VPT * 4;
+    const unsigned blocks = (unsigned)((n_eff + per_block - 1) / per_block);
+    hipLaunchKernelGGL(select_window_hist_kernel, dim3(blocks, nq), dim3(FA_THREADS), 0, st, scores, n_eff, sstride, c->hist);
+    hipLaunchKernelGGL(select_window_filter_kernel, dim3(blocks, nq), dim3(FA_THREADS), 0, st, scores, n_eff, sstride,
+                       (uint32_t)count, c->hist, c->cand);
+    hipLaunchKernelGGL(select_final_kernel, dim3(nq), dim3(FINAL_THREADS), 0, st, scores, n_eff, sstride, k, count, 0,
+                       c->hist, c->cand, idx->row_offset, out_s, out_r);
+  } else {
+    int64_t npad;
+    next_pow2_i64(n_eff, &npad);
+    if ((rc = grow_dev(&c->keys, &c->keys_cap, (size_t)nq * (size_t)npad)) != SVS_OK) return rc;
+    int gb = (int)std::min<int64_t>((npad + 255) / 256, 4096);
+    hipLaunchKernelGGL(keys_build_kernel, dim3(gb, nq), dim3(256), 0, st, scores, n_eff, sstride, npad, c->keys);
+    const int64_t chunk = std::min<int64_t>(npad, SORT_CAP);
+    hipLaunchKernelGGL(bitonic_local_kernel, dim3((unsigned)(npad / chunk), nq), dim3(SORT_THREADS), 0, st, c->keys, npad, 0, 1);
+    for (int64_t size = 2 * (int64_t)SORT_CAP; size <= npad; size <<= 1) {
+      for (int64_t stride = size >> 1; stride >= SORT_CAP; stride >>= 1) {
+        int g2 = (int)std::min<int64_t>(((npad >> 1) + 255) / 256, 8192);
+        hipLaunchKernelGGL(bitonic_global_kernel, dim3(g2, nq), dim3(256), 0, st, c->keys, npad, size, stride);
+      }
+      hipLaunchKernelGGL(bitonic_local_kernel, dim3((unsigned)(npad / chunk), nq), dim3(SORT_THREADS), 0, st, c->keys, npad, size, 0);
+    }
+    int ge = std::min((k + 255) / 256, 1024);
+    hipLaunchKernelGGL(keys_emit_kernel, dim3(ge, nq), dim3(256), 0, st, c->keys, npad, k, count,
+                       idx->row_offset, out_s, out_r);
+  }
+  return SVS_OK;
+}
+
+constexpr int64_t FUSE_PREFIX_ROWS = 16384;  // rows whose exact k-th best seeds the fused epilogue's thresholds
+
 int enqueue_search(svs_index* idx, Ctx* c, const float* q_dev, int nq, int k, int count,
                    float* out_s, int64_t* out_r, hipStream_t st, bool allow_fused = false) {
   const int64_t n = idx->n;
-  const int64_t sstride = (n + 3) & ~(int64_t)3;  // float4-aligned score vectors
   int rc;
   const bool path_a = k > 0 && n > SORT_CAP && count <= SEL_KMAX;
   // Fused top-k epilogue (no score matrix): batched f16 GEMM only; a query whose
   // candidate list overflows comes back marked and is re-run by the caller.
-  const bool fused = allow_fused && path_a && nq >= 64 && f16_tiled_ok(idx) && idx->variant.load() != 6;
-  if (!fused && (rc = grow_dev(&c->scores, &c->scores_cap, (size_t)nq * (size_t)sstride)) != SVS_OK) return rc;
+  const bool fused = allow_fused && path_a && nq >= 64 && n >= 8 * FUSE_PREFIX_ROWS && f16_tiled_ok(idx) &&
+                     idx->variant.load() != 6;
+  const int64_t n_mat = fused ? FUSE_PREFIX_ROWS : n;        // rows of the materialised score matrix
+  const int64_t sstride = (n_mat + 3) & ~(int64_t)3;         // float4-aligned score vectors
+  if ((rc = grow_dev(&c->scores, &c->scores_cap, (size_t)nq * (size_t)sstride)) != SVS_OK) return rc;
   if (path_a && (size_t)nq > c->hist_cap) {
     if (c->hist) HIP_TRY(hipFree(c->hist));
     if (c->cand) HIP_TRY(hipFree(c->cand));
@@ -430,59 +479,35 @@ int enqueue_search(svs_index* idx, Ctx* c, const float* q_dev, int nq, int k, in
     HIP_TRY(hipEventCreate(&ev.e2));
     HIP_TRY(hipEventRecord(ev.e0, st));
   }
-  if (nq >= 2 && batch_kernel_ok(idx)) {
-    for (int q0 = 0; q0 < nq; q0 += GQ) {
-      rc = launch_scores_q16(idx, c, q_dev + (size_t)q0 * idx->d, std::min(GQ, nq - q0),
-                             c->scores + (size_t)q0 * sstride, sstride, st);
-      if (rc != SVS_OK) return rc;
-    }
-  } else if (nq >= 2 && f16_tiled_ok(idx)) {
-    FuseLaunch fl;
-    if (fused) fl = FuseLaunch{c->hist, c->cand, (uint32_t)count};
-    rc = launch_scores_f16_tiled(idx, c, q_dev, nq, fused ? nullptr : c->scores, sstride, fl, st);
-    if (rc != SVS_OK) return rc;
+  if (fused) {
+    // 1. thresholds: exact k-th best of the first FUSE_PREFIX_ROWS rows, per query
+    if ((rc = grow_dev(&c->pref_s, &c->pref_s_cap, (size_t)nq * count)) != SVS_OK) return rc;
+    if ((rc = grow_dev(&c->pref_r, &c->pref_r_cap, (size_t)nq * count)) != SVS_OK) return rc;
+    if ((rc = launch_scores_f16_tiled(idx, c, q_dev, n_mat, nq, c->scores, sstride, FuseLaunch{}, st)) != SVS_OK) return rc;
+    if ((rc = run_select(idx, c, c->scores, n_mat, sstride, nq, count, count, c->pref_s, c->pref_r, st)) != SVS_OK) return rc;
+    // 2. the whole corpus, keeping only scores >= threshold
+    FuseLaunch fl{c->hist, c->cand, c->pref_s + (count - 1), count};
+    if ((rc = launch_scores_f16_tiled(idx, c, q_dev, n, nq, nullptr, 0, fl, st, false)) != SVS_OK) return rc;
+    if (timed) HIP_TRY(hipEventRecord(ev.e1, st));
+    hipLaunchKernelGGL(select_final_kernel, dim3(nq), dim3(FINAL_THREADS), 0, st, (const float*)nullptr, n, (int64_t)0, k, count, 3,
+                       c->hist, c->cand, idx->row_offset, out_s, out_r);
   } else {
-    for (int qi = 0; qi < nq; ++qi) {
-      rc = launch_scores(idx, c, q_dev + (size_t)qi * idx->d, c->scores + (size_t)qi * sstride, st);
-      if (rc != SVS_OK) return rc;
-    }
-  }
-  if (timed) HIP_TRY(hipEventRecord(ev.e1, st));
-
-  if (k > 0) {
-    if (n <= SORT_CAP) {
-      hipLaunchKernelGGL(select_final_kernel, dim3(nq), dim3(FINAL_THREADS), 0, st, c->scores, n, sstride, k,
-                         count, 1, (uint32_t*)nullptr, (const uint64_t*)nullptr, idx->row_offset, out_s, out_r);
-    } else if (fused) {
-      hipLaunchKernelGGL(select_final_kernel, dim3(nq), dim3(FINAL_THREADS), 0, st, (const float*)nullptr, n, sstride, k, count, 3,
-                         c->hist, c->cand, idx->row_offset, out_s, out_r);
-    } else if (path_a) {
-      const int64_t per_block = (int64_t)FA_THREADS * SEL_VPT * 4;
-      const unsigned blocks = (unsigned)((n + per_block - 1) / per_block);
-      hipLaunchKernelGGL(select_window_hist_kernel, dim3(blocks, nq), dim3(FA_THREADS), 0, st, c->scores, n, sstride, c->hist);
-      hipLaunchKernelGGL(select_window_filter_kernel, dim3(blocks, nq), dim3(FA_THREADS), 0, st, c->scores, n, sstride,
-                         (uint32_t)count, c->hist, c->cand);
-      hipLaunchKernelGGL(select_final_kernel, dim3(nq), dim3(FINAL_THREADS), 0, st, c->scores, n, sstride, k, count, 0,
-                         c->hist, c->cand, idx->row_offset, out_s, out_r);
-    } else {
-      int64_t npad;
-      next_pow2_i64(n, &npad);
-      if ((rc = grow_dev(&c->keys, &c->keys_cap, (size_t)nq * (size_t)npad)) != SVS_OK) return rc;
-      int gb = (int)std::min<int64_t>((npad + 255) / 256, 4096);
-      hipLaunchKernelGGL(keys_build_kernel, dim3(gb, nq), dim3(256), 0, st, c->scores, n, sstride, npad, c->keys);
-      const int64_t chunk = std::min<int64_t>(npad, SORT_CAP);
-      hipLaunchKernelGGL(bitonic_local_kernel, dim3((unsigned)(npad / chunk), nq), dim3(SORT_THREADS), 0, st, c->keys, npad, 0, 1);
-      for (int64_t size = 2 * (int64_t)SORT_CAP; size <= npad; size <<= 1) {
-        for (int64_t stride = size >> 1; stride >= SORT_CAP; stride >>= 1) {
-          int g2 = (int)std::min<int64_t>(((npad >> 1) + 255) / 256, 8192);
-          hipLaunchKernelGGL(bitonic_global_kernel, dim3(g2, nq), dim3(256), 0, st, c->keys, npad, size, stride);
-        }
-        hipLaunchKernelGGL(bitonic_local_kernel, dim3((unsigned)(npad / chunk), nq), dim3(SORT_THREADS), 0, st, c->keys, npad, size, 0);
+    if (nq >= 2 && batch_kernel_ok(idx)) {
+      for (int q0 = 0; q0 < nq; q0 += GQ) {
+        rc = launch_scores_q16(idx, c, q_dev + (size_t)q0 * idx->d, std::min(GQ, nq - q0),
+                               c->scores + (size_t)q0 * sstride, sstride, st);
+        if (rc != SVS_OK) return rc;
       }
-      int ge = std::min((k + 255) / 256, 1024);
-      hipLaunchKernelGGL(keys_emit_kernel, dim3(ge, nq), dim3(256), 0, st, c->keys, npad, k, count,
-                         idx->row_offset, out_s, out_r);
+    } else if (nq >= 2 && f16_tiled_ok(idx)) {
+      if ((rc = launch_scores_f16_tiled(idx, c, q_dev, n, nq, c->scores, sstride, FuseLaunch{}, st)) != SVS_OK) return rc;
+    } else {
+      for (int qi = 0; qi < nq; ++qi) {
+        rc = launch_scores(idx, c, q_dev + (size_t)qi * idx->d, c->scores + (size_t)qi * sstride, st);
+        if (rc != SVS_OK) return rc;
+      }
     }
+    if (timed) HIP_TRY(hipEventRecord(ev.e1, st));
+    if (k > 0 && (rc = run_select(idx, c, c->scores, n, sstride, nq, k, count, out_s, out_r, st)) != SVS_OK) return rc;
   }
   HIP_TRY(hipGetLastError());
   if (timed) {

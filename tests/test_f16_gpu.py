@@ -63,10 +63,12 @@ def test_f16_recall_vs_f32(gpu):
     assert min(rec) >= 0.95, rec
 
 
-@pytest.mark.parametrize("n,d,nq,k", [(40000, 1536, 64, 100), (25000, 768, 100, 10), (20000, 512, 300, 100)])
+@pytest.mark.parametrize("n,d,nq,k", [(140000, 768, 64, 100), (131072, 256, 100, 10), (150001, 512, 300, 100),
+                                      (40000, 1536, 64, 100)])
 def test_f16_large_batch_fused_topk(gpu, n, d, nq, k):
-    """nq >= 64 takes the tiled MFMA GEMM with the fused top-k epilogue (the score
-    matrix is never materialised)."""
+    """nq >= 64 over >= 131,072 rows takes the tiled MFMA GEMM with the fused top-k
+    epilogue (the score matrix is never materialised; thresholds come from a
+    16,384-row prefix); smaller corpora take the materialised path."""
     from svs_amd import DeviceIndex
     m, qs = corpus_and_query("gaussian", 7000 + n, n, d, nq)
     idx = DeviceIndex(m, dtype="f16")
@@ -90,7 +92,7 @@ def test_f16_fused_overflow_falls_back_exactly(gpu):
     re-run through the materialised path and still be exact."""
     from svs_amd import DeviceIndex
     rng = np.random.default_rng(11)
-    n, d, nq, k = 120000, 64, 70, 50
+    n, d, nq, k = 150000, 64, 70, 50
     u = rng.standard_normal(d); u /= np.linalg.norm(u)
     v = rng.standard_normal((n, d)); v -= np.outer(v @ u, u); v /= np.linalg.norm(v, axis=1, keepdims=True)
     c = np.linspace(0.05, 0.95, n)[:, None]                 # cosine to u grows with the row
