@@ -11,8 +11,9 @@
 // Structure (gfx950): workgroup tile = 128 corpus rows x BN queries, BK = 64 halves
 // (exactly ONE 128-byte line per row per k-step), 8 waves.  Both operand tiles
 // are staged HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPRs, every
-// wave instruction moves 8 rows x 128 B of whole lines), double buffered: the
-// DMA of step s+1 is in flight while step s is multiplied.  The LDS image is
+// wave instruction moves 8 rows x 128 B of whole lines) through a three-buffer
+// ring: the DMA of steps s+1 and s+2 is in flight while step s is multiplied
+// (counted vmcnt + raw s_barrier, never vmcnt(0) inside the loop).  The LDS image is
 // linear (the DMA writes base + lane*16), so the bank-conflict swizzle is put on
 // the SOURCE address: physical 16-byte chunk c of row r holds global chunk
 // c ^ ((r >> 1) & 7), and fragment reads apply the same XOR -- conflict-free
@@ -62,10 +63,18 @@ __device__ __forceinline__ void fuse_offer(uint32_t* hdr, uint64_t* cand, uint32
 // rows [row0, row0+rows) of a row-major half matrix with stride ld; rows past
 // row_max are clamped (their products are never stored).  One wave instruction
 // covers 8 rows; the workgroup's waves take instructions round-robin.
-__device__ __forceinline__ void tg_stage(const _Float16* __restrict__ base, int64_t row0, int rows,
+// Every wave issues the SAME number of DMA instructions, max(1, rows/64) (with
+// fewer than 8 instructions in all, the surplus waves repeat one -- same bytes to
+// the same place), so a counted s_waitcnt vmcnt(N) means the same thing in every wave.
+template <int ROWS>
+__device__ __forceinline__ void tg_stage(const _Float16* __restrict__ base, int64_t row0,
                                          int64_t row_max, int ld, int s, u32x4* lds, int wave, int lane) {
+  constexpr int NI = ROWS / 8;                       // wave instructions in the tile
+  constexpr int PER = NI >= TG_WAVES ? NI / TG_WAVES : 1;
   const int r_in = lane >> 3, pc = lane & 7;
-  for (int i = wave; i < (rows >> 3); i += TG_WAVES) {
+#pragma unroll
+  for (int t = 0; t < PER; ++t) {
+    const int i = (wave + t * TG_WAVES) % NI;
     const int r = i * 8 + r_in;
     int64_t gr = row0 + r;
     gr = gr < row_max ? gr : row_max - 1;
@@ -75,6 +84,8 @@ __device__ __forceinline__ void tg_stage(const _Float16* __restrict__ base, int6
                                      (__attribute__((address_space(3))) void*)(lds + i * 64), 16, 0, 0);
   }
 }
+
+template <int ROWS> constexpr int tg_stage_count() { return ROWS / 8 >= TG_WAVES ? ROWS / 8 / TG_WAVES : 1; }
 
 // Q: [nq_pad][ld] halves, nq_pad a multiple of BN (rows >= nq zero).
 // FUSE == false: scores [nq][sstride] are written.  FUSE == true: nothing is
@@ -92,9 +103,11 @@ __global__ __launch_bounds__(TG_WAVES * 64) void gemm_f16_tiled_kernel(
   constexpr int MT = TM / 16, NT = TN / 16; // MFMA tiles per wave
   static_assert(TM % 16 == 0 && TN % 16 == 0, "wave tile must be whole MFMA tiles");
   extern __shared__ u32x4 tg_lds[];
-  // layout: A buffers [2][128 rows][8 chunks], then B buffers [2][BN rows][8 chunks]
+  // layout: A buffers [NBUF][128 rows][8 chunks], then B buffers [NBUF][BN rows][8 chunks]
+  constexpr int NBUF = 3;
   auto ldsA = [&](int b) { return tg_lds + b * (TG_BM * 8); };
-  auto ldsB = [&](int b) { return tg_lds + 2 * TG_BM * 8 + b * (BN * 8); };
+  auto ldsB = [&](int b) { return tg_lds + NBUF * TG_BM * 8 + b * (BN * 8); };
+  constexpr int DMA_PER_STAGE = tg_stage_count<TG_BM>() + tg_stage_count<BN>();
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -110,15 +123,27 @@ __global__ __launch_bounds__(TG_WAVES * 64) void gemm_f16_tiled_kernel(
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  tg_stage(M, row0, TG_BM, n, ld, 0, ldsA(0), wave, lane);
-  tg_stage(Q, q0, BN, (int64_t)q0 + BN, ld, 0, ldsB(0), wave, lane);
-  __syncthreads();  // hipcc drains the LDS-DMA (vmcnt(0)) in front of the barrier
-
+  // Three-stage ring, two k-steps of LDS-DMA in flight while one is multiplied.
+  // The DMA is ordered for the readers only by the issuing waves' counted vmcnt
+  // followed by a barrier every reader has passed, hence: wait (all but the next
+  // step's DMA retired) -> raw s_barrier -> issue step s+2 into the buffer that
+  // was read in step s-1 (everyone is past that read: same barrier) -> multiply
+  // step s.  A plain __syncthreads() would make hipcc drain vmcnt(0) every step.
+  tg_stage<TG_BM>(M, row0, n, ld, 0, ldsA(0), wave, lane);
+  tg_stage<BN>(Q, q0, (int64_t)q0 + BN, ld, 0, ldsB(0), wave, lane);
+  if (ksteps > 1) {
+    tg_stage<TG_BM>(M, row0, n, ld, 1, ldsA(1), wave, lane);
+    tg_stage<BN>(Q, q0, (int64_t)q0 + BN, ld, 1, ldsB(1), wave, lane);
+  }
+  int cur = 0;
   for (int s = 0; s < ksteps; ++s) {
-    const int cur = s & 1;
-    if (s + 1 < ksteps) {
-      tg_stage(M, row0, TG_BM, n, ld, s + 1, ldsA(cur ^ 1), wave, lane);
-      tg_stage(Q, q0, BN, (int64_t)q0 + BN, ld, s + 1, ldsB(cur ^ 1), wave, lane);
+    if (s + 1 < ksteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_STAGE) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (s + 2 < ksteps) {
+      const int nb = cur >= 1 ? cur - 1 : NBUF - 1;   // (s + 2) % 3
+      tg_stage<TG_BM>(M, row0, n, ld, s + 2, ldsA(nb), wave, lane);
+      tg_stage<BN>(Q, q0, (int64_t)q0 + BN, ld, s + 2, ldsB(nb), wave, lane);
     }
     const u32x4* A = ldsA(cur);
     const u32x4* B = ldsB(cur);
@@ -141,7 +166,7 @@ __global__ __launch_bounds__(TG_WAVES * 64) void gemm_f16_tiled_kernel(
         for (int j = 0; j < NT; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
-    __syncthreads();  // everyone is done reading `cur`; the DMA into `cur ^ 1` has landed
+    cur = cur + 1 < NBUF ? cur + 1 : 0;
   }
 
   // D layout: column (query) = lane & 15, rows 4 g + r of each 16-row tile

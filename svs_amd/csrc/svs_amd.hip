@@ -377,10 +377,10 @@ template <int BN, bool FUSE>
 int launch_f16_tiled_bn(const svs_index* idx, Ctx* c, int64_t n_rows, int nq, float* scores, int64_t sstride,
                         FuseLaunch fl, hipStream_t st) {
   static std::once_flag once;
-  const size_t lds = (size_t)(2 * TG_BM * 8 + 2 * BN * 8) * sizeof(u32x4);
+  const size_t lds = (size_t)(3 * TG_BM * 8 + 3 * BN * 8) * sizeof(u32x4);
   std::call_once(once, [] {
     (void)hipFuncSetAttribute((const void*)gemm_f16_tiled_kernel<BN, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)((2 * TG_BM * 8 + 2 * BN * 8) * sizeof(u32x4)));
+                              (int)((3 * TG_BM * 8 + 3 * BN * 8) * sizeof(u32x4)));
   });
   const unsigned gx = (unsigned)((n_rows + TG_BM - 1) / TG_BM), gy = (unsigned)((nq + BN - 1) / BN);
   hipLaunchKernelGGL((gemm_f16_tiled_kernel<BN, FUSE>), dim3(gx, gy), dim3(TG_WAVES * 64), lds, st,
