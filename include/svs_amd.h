@@ -45,9 +45,12 @@ typedef enum svs_status {
 /* element type of the HBM-resident corpus (the arithmetic stays f32-accumulate) */
 typedef enum svs_dtype {
   SVS_DTYPE_F32 = 0, /* reference layout: np.zeros((n, m), float32), src/svs/kb.py:600 */
-  SVS_DTYPE_F16 = 1  /* extension for BASELINE.json configs[2]/[3]: rows AND queries rounded to IEEE
+  SVS_DTYPE_F16 = 1, /* extension for BASELINE.json configs[2]/[3]: rows AND queries rounded to IEEE
                         half (RNE), products exact in f32, f32 accumulate.  Parity oracle: numpy's
                         f32 path on the dequantised corpus and query. */
+  SVS_DTYPE_FP8 = 2  /* extension for BASELINE.json configs[4]: OCP e4m3fn rows with one f32 scale per
+                        row (max|x| -> 448), queries quantised the same way; score = scale_row *
+                        scale_query * sum(q8 * q8) accumulated in f32.  Same oracle rule. */
 } svs_dtype;
 
 typedef struct svs_index_info_t {
@@ -127,6 +130,14 @@ int32_t svs_index_search_device(svs_index* idx, const float* dev_queries, int32_
 /* All scores of one query, f32 (n) to host: the raw `np.dot(M, q)` vector
  * (src/svs/kb.py:1623) for callers that want it and for parity tests. */
 int32_t svs_index_scores(svs_index* idx, const float* query, int32_t d, float* out_scores);
+
+/* ---- parity support (tests): what the index really holds -------------------- */
+/* Rows [row0, row0 + nrows) exactly as stored, dequantised to f32 (nrows x d,
+ * C-contiguous, host).  f32: the rows; f16: half-rounded; fp8: e4m3 * row scale. */
+int32_t svs_index_debug_dequant(svs_index* idx, int64_t row0, int64_t nrows, float* out);
+/* The query as the kernels of this index's dtype see it (f32: unchanged; f16:
+ * half-rounded; fp8: quantised with its own scale and dequantised), d floats, host. */
+int32_t svs_index_debug_query(svs_index* idx, const float* query, int32_t d, float* out);
 
 /* ---- measurement --------------------------------------------------------- */
 /* enable != 0: record HIP events around the score and select stages of every

@@ -22,6 +22,7 @@ SVS_ERR_UNSUPPORTED = -5
 
 DTYPE_F32 = 0
 DTYPE_F16 = 1
+DTYPE_FP8 = 2
 
 
 class IndexInfo(C.Structure):
@@ -58,6 +59,8 @@ SIGNATURES = {
     "svs_index_search": (C.c_int32, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.POINTER(C.c_int32)]),
     "svs_index_search_device": (C.c_int32, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.POINTER(C.c_int32), _P]),
     "svs_index_scores": (C.c_int32, [_P, _P, C.c_int32, _P]),
+    "svs_index_debug_dequant": (C.c_int32, [_P, C.c_int64, C.c_int64, _P]),
+    "svs_index_debug_query": (C.c_int32, [_P, _P, C.c_int32, _P]),
     "svs_index_set_timing": (C.c_int32, [_P, C.c_int32]),
     "svs_index_get_timing": (C.c_int32, [_P, C.POINTER(Timing)]),
     "svs_index_set_variant": (C.c_int32, [_P, C.c_int32]),

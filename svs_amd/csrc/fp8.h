@@ -1,0 +1,131 @@
+// fp8-resident corpus (SVS_DTYPE_FP8; BASELINE.json configs[4]: 10M x 3072).
+// OCP e4m3fn (gfx950's native fp8, NOT the MI300 fnuz encoding) with one f32
+// scale per row: unit-norm rows have |x| ~ 1/sqrt(d) ~ 0.02, at the very bottom
+// of e4m3's normal range (2^-6), so each row is scaled to put its largest
+// magnitude on 448 (the e4m3 maximum) before rounding (RNE):
+//     scale_i = max_d |M[i,d]| / 448        q8[i,d] = e4m3(M[i,d] / scale_i)
+// Queries are quantised the same way.  A score is
+//     scale_i * scale_q * sum_d f32(q8[i,d]) * f32(q8q[d])      (f32 accumulate)
+// and the parity oracle for this dtype is numpy's f32 path on the DEQUANTISED
+// corpus and query (svs_index_debug_dequant returns exactly what is stored).
+// Recall against the f32 corpus is a property of the rounding, reported separately.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gemv_f32.h"
+
+namespace svs {
+
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr float FP8_MAX = 448.0f;
+
+// 4 floats -> 4 packed e4m3 bytes (RNE)
+__device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d) {
+  int p = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  p = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, p, true);
+  return (uint32_t)p;
+}
+__device__ __forceinline__ void unpack_fp8x4(uint32_t p, float (&o)[4]) {
+  const f32x2_t lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)p, false);
+  const f32x2_t hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)p, true);
+  o[0] = lo.x; o[1] = lo.y; o[2] = hi.x; o[3] = hi.y;
+}
+
+// One wave per row: f32 row (stride src_ld) -> e4m3 row (stride ld8 bytes, zero
+// padded) + scale.  Optionally also the quantised values back as f32 (qf, stride
+// ld8 floats): the single-query kernel reads the query that way.
+__global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(
+    const float* __restrict__ src, int64_t n, int d, int64_t src_ld, uint8_t* __restrict__ dst, int ld8,
+    float* __restrict__ scales, float* __restrict__ qf) {
+  const int lane = threadIdx.x & 63;
+  const int64_t gw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t W = (int64_t)gridDim.x * 4;
+  for (int64_t row = gw; row < n; row += W) {
+    const float* s = src + row * src_ld;
+    float mx = 0.f;
+    for (int c = lane; c < d; c += 64) mx = fmaxf(mx, fabsf(s[c]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    const float scale = mx > 0.f ? mx / FP8_MAX : 1.0f;
+    const float inv = 1.0f / scale;
+    if (lane == 0) scales[row] = scale;
+    uint32_t* o = (uint32_t*)(dst + row * ld8);
+    for (int c4 = lane; c4 < ld8 / 4; c4 += 64) {
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = c4 * 4 + e;
+        v[e] = c < d ? s[c] * inv : 0.f;
+      }
+      const uint32_t p = pack_fp8x4(v[0], v[1], v[2], v[3]);
+      o[c4] = p;
+      if (qf) {
+        float b[4];
+        unpack_fp8x4(p, b);
+        float* q = qf + row * ld8 + c4 * 4;
+        q[0] = b[0]; q[1] = b[1]; q[2] = b[2]; q[3] = b[3];
+      }
+    }
+  }
+}
+
+// debug / parity: stored rows back as f32 (value * scale), out stride d
+__global__ void dequant_rows_fp8_kernel(const uint8_t* __restrict__ rows, const float* __restrict__ scales,
+                                        int64_t row0, int64_t nrows, int d, int ld8, float* __restrict__ out) {
+  const int64_t total = nrows * d;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t r = i / d;
+    const int c = (int)(i - r * d);
+    const uint8_t b = rows[(row0 + r) * ld8 + c];
+    out[i] = __builtin_amdgcn_cvt_f32_fp8((int)b, 0) * scales[row0 + r];
+  }
+}
+
+// 16 e4m3 bytes (one 16-byte load) times 16 f32 query values
+__device__ __forceinline__ float dot16_fp8(u32x4_t a, const v4f* q, float acc) {
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const uint32_t p = w == 0 ? a.x : (w == 1 ? a.y : (w == 2 ? a.z : a.w));
+    float v[4];
+    unpack_fp8x4(p, v);
+    const v4f qq = q[w];
+    acc = fmaf(v[0], qq.x, acc);
+    acc = fmaf(v[1], qq.y, acc);
+    acc = fmaf(v[2], qq.z, acc);
+    acc = fmaf(v[3], qq.w, acc);
+  }
+  return acc;
+}
+
+// ---- single query: T lanes per row, 64/T rows per wave step --------------------
+// M: e4m3 rows (ld8 bytes, multiple of 16); qf: the quantised query as f32 (ld8
+// floats, zero padded); score = row scale * query scale * dot.
+template <int T>
+__global__ __launch_bounds__(256) void gemv_fp8_kernel(
+    const u32x4_t* __restrict__ M, const float* __restrict__ row_scales, const v4f* __restrict__ qf,
+    const float* __restrict__ q_scale, float* __restrict__ scores, int64_t n, int ld16) {
+  constexpr int RPW = 64 / T;
+  const int lane = threadIdx.x & 63;
+  const int sub = lane & (T - 1);
+  const int rsub = lane / T;
+  const int64_t gw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t W = (int64_t)gridDim.x * 4;
+  const float sq = q_scale[0];
+  for (int64_t base = gw * RPW; base < n; base += W * RPW) {
+    int64_t row = base + rsub;
+    const bool live = row < n;
+    row = live ? row : n - 1;
+    const u32x4_t* p = M + row * ld16;
+    float acc = 0.f;
+    for (int c = sub; c < ld16; c += T) acc = dot16_fp8(__builtin_nontemporal_load(p + c), qf + c * 4, acc);
+#pragma unroll
+    for (int off = T / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (sub == 0 && live) scores[row] = acc * row_scales[row] * sq;
+  }
+}
+
+}  // namespace svs

@@ -1,6 +1,9 @@
-// Batched score stage for an f16 corpus: LDS-tiled MFMA GEMM
-//     S[j][i] = sum_d half(M[i,d]) * half(Q[j,d])   (f32 accumulate)
-// for BASELINE.json configs[2] (1M x 1536 f16, 1024 queries).  The reference's
+// Batched score stage for f16 and fp8 corpora: LDS-tiled MFMA GEMM
+//     S[j][i] = sum_d M8/16[i,d] * Q8/16[j,d]   (f32 accumulate; x scales for fp8)
+// for BASELINE.json configs[2] (1M x 1536 f16, 1024 queries) and configs[4]
+// (10M x 3072 fp8, 256 queries).  EB = bytes per element: 2 -> half operands on
+// v_mfma_f32_16x16x32_f16, 1 -> e4m3 operands on v_mfma_f32_16x16x32_fp8_fp8 (a
+// k-step is always 128 BYTES per row: 64 halves or 128 fp8).  The reference's
 // nearest analogue is its np.dot(M, M.T) (src/svs/kb.py:1651); a query batch is
 // by definition a loop of np.dot(M, q) calls (src/svs/kb.py:1623).
 //
@@ -25,6 +28,7 @@
 #include <stdint.h>
 
 #include "gemm_f32.h"
+#include "fp8.h"
 #include "gemv_f16.h"
 #include "keys.h"
 
@@ -33,7 +37,7 @@ namespace svs {
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int TG_BM = 128;  // corpus rows per workgroup tile
-constexpr int TG_BK = 64;   // halves per k-step (128 B per row)
+constexpr int TG_BKB = 128;  // BYTES per row per k-step (one 128-byte line)
 constexpr int TG_WAVES = 8;
 
 __device__ __forceinline__ int tg_swz(int row) { return (row >> 1) & 7; }
@@ -67,8 +71,8 @@ __device__ __forceinline__ void fuse_offer(uint32_t* hdr, uint64_t* cand, uint32
 // fewer than 8 instructions in all, the surplus waves repeat one -- same bytes to
 // the same place), so a counted s_waitcnt vmcnt(N) means the same thing in every wave.
 template <int ROWS>
-__device__ __forceinline__ void tg_stage(const _Float16* __restrict__ base, int64_t row0,
-                                         int64_t row_max, int ld, int s, u32x4* lds, int wave, int lane) {
+__device__ __forceinline__ void tg_stage(const uint8_t* __restrict__ base, int64_t row0,
+                                         int64_t row_max, int64_t ldb, int s, u32x4* lds, int wave, int lane) {
   constexpr int NI = ROWS / 8;                       // wave instructions in the tile
   constexpr int PER = NI >= TG_WAVES ? NI / TG_WAVES : 1;
   const int r_in = lane >> 3, pc = lane & 7;
@@ -79,7 +83,7 @@ __device__ __forceinline__ void tg_stage(const _Float16* __restrict__ base, int6
     int64_t gr = row0 + r;
     gr = gr < row_max ? gr : row_max - 1;
     const int gc = pc ^ tg_swz(r);
-    const _Float16* src = base + gr * ld + s * TG_BK + gc * 8;
+    const uint8_t* src = base + gr * ldb + s * TG_BKB + gc * 16;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)(lds + i * 64), 16, 0, 0);
   }
@@ -91,11 +95,14 @@ template <int ROWS> constexpr int tg_stage_count() { return ROWS / 8 >= TG_WAVES
 // FUSE == false: scores [nq][sstride] are written.  FUSE == true: nothing is
 // materialised; scores >= fthr[q * fthr_stride] go to fcand [nq][fcap], counted in
 // the per-query header word fstate_words[q * fstate_stride].
-template <int BN, bool FUSE>
-__global__ __launch_bounds__(TG_WAVES * 64) void gemm_f16_tiled_kernel(
-    const _Float16* __restrict__ M, const _Float16* __restrict__ Q, float* __restrict__ scores,
-    int64_t n, int ld, int64_t sstride, int nq, uint32_t* __restrict__ fstate_words, int fstate_stride,
-    uint64_t* __restrict__ fcand, uint32_t fcap, const float* __restrict__ fthr, int fthr_stride) {
+// ldb = row stride in BYTES (multiple of 128) of both M and Q.  EB == 1: the
+// accumulators are multiplied by rscale[row] * qscale[query] before use.
+template <int BN, bool FUSE, int EB>
+__global__ __launch_bounds__(TG_WAVES * 64) void gemm_tiled_kernel(
+    const uint8_t* __restrict__ M, const uint8_t* __restrict__ Q, float* __restrict__ scores,
+    int64_t n, int64_t ldb, int64_t sstride, int nq, uint32_t* __restrict__ fstate_words, int fstate_stride,
+    uint64_t* __restrict__ fcand, uint32_t fcap, const float* __restrict__ fthr, int fthr_stride,
+    const float* __restrict__ rscale, const float* __restrict__ qscale) {
   constexpr int TN = BN < 64 ? BN : 64;     // queries per wave tile
   constexpr int WN = BN / TN;               // waves along the query axis
   constexpr int WM = TG_WAVES / WN;         // waves along the row axis
@@ -115,7 +122,7 @@ __global__ __launch_bounds__(TG_WAVES * 64) void gemm_f16_tiled_kernel(
   const int r16 = lane & 15, g = lane >> 4;
   const int64_t row0 = (int64_t)blockIdx.x * TG_BM;
   const int q0 = blockIdx.y * BN;
-  const int ksteps = ld / TG_BK;
+  const int ksteps = (int)(ldb / TG_BKB);
 
   f32x4_t acc[MT][NT];
 #pragma unroll
@@ -129,11 +136,11 @@ __global__ __launch_bounds__(TG_WAVES * 64) void gemm_f16_tiled_kernel(
   // step's DMA retired) -> raw s_barrier -> issue step s+2 into the buffer that
   // was read in step s-1 (everyone is past that read: same barrier) -> multiply
   // step s.  A plain __syncthreads() would make hipcc drain vmcnt(0) every step.
-  tg_stage<TG_BM>(M, row0, n, ld, 0, ldsA(0), wave, lane);
-  tg_stage<BN>(Q, q0, (int64_t)q0 + BN, ld, 0, ldsB(0), wave, lane);
+  tg_stage<TG_BM>(M, row0, n, ldb, 0, ldsA(0), wave, lane);
+  tg_stage<BN>(Q, q0, (int64_t)q0 + BN, ldb, 0, ldsB(0), wave, lane);
   if (ksteps > 1) {
-    tg_stage<TG_BM>(M, row0, n, ld, 1, ldsA(1), wave, lane);
-    tg_stage<BN>(Q, q0, (int64_t)q0 + BN, ld, 1, ldsB(1), wave, lane);
+    tg_stage<TG_BM>(M, row0, n, ldb, 1, ldsA(1), wave, lane);
+    tg_stage<BN>(Q, q0, (int64_t)q0 + BN, ldb, 1, ldsB(1), wave, lane);
   }
   int cur = 0;
   for (int s = 0; s < ksteps; ++s) {
@@ -142,29 +149,54 @@ __global__ __launch_bounds__(TG_WAVES * 64) void gemm_f16_tiled_kernel(
     __builtin_amdgcn_s_barrier();
     if (s + 2 < ksteps) {
       const int nb = cur >= 1 ? cur - 1 : NBUF - 1;   // (s + 2) % 3
-      tg_stage<TG_BM>(M, row0, n, ld, s + 2, ldsA(nb), wave, lane);
-      tg_stage<BN>(Q, q0, (int64_t)q0 + BN, ld, s + 2, ldsB(nb), wave, lane);
+      tg_stage<TG_BM>(M, row0, n, ldb, s + 2, ldsA(nb), wave, lane);
+      tg_stage<BN>(Q, q0, (int64_t)q0 + BN, ldb, s + 2, ldsB(nb), wave, lane);
     }
     const u32x4* A = ldsA(cur);
     const u32x4* B = ldsB(cur);
+    if constexpr (EB == 2) {
 #pragma unroll
-    for (int kh = 0; kh < 2; ++kh) {
-      h8 fa[MT], fb[NT];
+      for (int kh = 0; kh < 2; ++kh) {   // two 32-wide k-halves; lane holds halves 8g..8g+7 = one 16-B chunk
+        h8 fa[MT], fb[NT];
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int r = wm * TM + i * 16 + r16;
-        fa[i] = __builtin_bit_cast(h8, A[r * 8 + ((4 * kh + g) ^ tg_swz(r))]);
+        for (int i = 0; i < MT; ++i) {
+          const int r = wm * TM + i * 16 + r16;
+          fa[i] = __builtin_bit_cast(h8, A[r * 8 + ((4 * kh + g) ^ tg_swz(r))]);
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int r = wn * TN + j * 16 + r16;
+          fb[j] = __builtin_bit_cast(h8, B[r * 8 + ((4 * kh + g) ^ tg_swz(r))]);
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
       }
+    } else {
+      const long* A8 = (const long*)A;
+      const long* B8 = (const long*)B;
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int r = wn * TN + j * 16 + r16;
-        fb[j] = __builtin_bit_cast(h8, B[r * 8 + ((4 * kh + g) ^ tg_swz(r))]);
+      for (int kq = 0; kq < 4; ++kq) {   // four 32-wide k-quarters; lane holds bytes 8g..8g+7 = half a chunk
+        long fa[MT], fb[NT];
+        const int chunk = 2 * kq + (g >> 1), half = g & 1;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int r = wm * TM + i * 16 + r16;
+          fa[i] = A8[(r * 8 + (chunk ^ tg_swz(r))) * 2 + half];
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int r = wn * TN + j * 16 + r16;
+          fb[j] = B8[(r * 8 + (chunk ^ tg_swz(r))) * 2 + half];
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(fa[i], fb[j], acc[i][j], 0, 0, 0);
       }
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
     cur = cur + 1 < NBUF ? cur + 1 : 0;
   }
@@ -174,6 +206,18 @@ __global__ __launch_bounds__(TG_WAVES * 64) void gemm_f16_tiled_kernel(
   for (int j = 0; j < NT; ++j) {
     const int query = q0 + wn * TN + j * 16 + r16;
     if (query < nq) {
+      if constexpr (EB == 1) {   // per-row and per-query dequantisation scales
+        const float qs = qscale[query];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int64_t ob = row0 + wm * TM + i * 16 + 4 * g;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int64_t rr = ob + r < n ? ob + r : n - 1;
+            acc[i][j][r] *= rscale[rr] * qs;
+          }
+        }
+      }
       if constexpr (FUSE) {
         uint32_t* hdr = fstate_words + (int64_t)query * fstate_stride;
         uint64_t* cq = fcand + (int64_t)query * fcap;

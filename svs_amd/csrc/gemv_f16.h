@@ -47,6 +47,17 @@ __global__ void convert_rows_f16_kernel(const float* __restrict__ src, int64_t n
   }
 }
 
+// debug / parity: half rows back as f32, out stride d
+__global__ void dequant_rows_f16_kernel(const _Float16* __restrict__ rows, int64_t row0, int64_t nrows, int d,
+                                        int ld16, float* __restrict__ out) {
+  const int64_t total = nrows * d;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t r = i / d;
+    out[i] = (float)rows[(row0 + r) * ld16 + (i - r * d)];
+  }
+}
+
 // queries f32 [nq][d] -> half [nq][ld16] zero padded (tiny)
 __global__ void convert_queries_f16_kernel(const float* __restrict__ q, int nq, int d,
                                            _Float16* __restrict__ dst, int ld16) {

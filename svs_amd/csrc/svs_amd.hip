@@ -16,7 +16,8 @@
 #include <string>
 #include <vector>
 
-#include "gemm_f16_tiled.h"
+#include "fp8.h"
+#include "gemm_tiled.h"
 #include "gemm_f32.h"
 #include "gemv_f16.h"
 #include "gemv_f32.h"
@@ -56,6 +57,9 @@ struct Ctx {
   float* q_dev = nullptr;       size_t q_cap = 0;        // floats
   float* q16 = nullptr;         size_t q16_cap = 0;      // [16][ld] zero-padded query group
   _Float16* qh = nullptr;       size_t qh_cap = 0;       // half queries, [rows][ld] zero padded
+  uint8_t* q8 = nullptr;        size_t q8_cap = 0;       // e4m3 queries [rows][ld], zero padded
+  float* q8f = nullptr;         size_t q8f_cap = 0;      // the same values as f32 (single-query kernel)
+  float* q8s = nullptr;         size_t q8s_cap = 0;      // query scales
   float* pref_s = nullptr;      size_t pref_s_cap = 0;   // fused GEMM: top-k of the prefix rows (thresholds)
   int64_t* pref_r = nullptr;    size_t pref_r_cap = 0;
   float* scores = nullptr;      size_t scores_cap = 0;   // floats
@@ -79,6 +83,7 @@ struct svs_index {
   int d = 0, ld = 0, dtype = SVS_DTYPE_F32;
   int64_t row_offset = 0;
   void* rows = nullptr;
+  float* row_scales = nullptr;   // fp8 only: one f32 per row
   size_t bytes = 0;
   int cu_count = 256;
 
@@ -102,6 +107,9 @@ void ctx_destroy(Ctx* c) {
   (void)hipFree(c->q_dev);
   (void)hipFree(c->q16);
   (void)hipFree(c->qh);
+  (void)hipFree(c->q8);
+  (void)hipFree(c->q8f);
+  (void)hipFree(c->q8s);
   (void)hipFree(c->pref_s);
   (void)hipFree(c->pref_r);
   (void)hipFree(c->scores);
@@ -124,6 +132,7 @@ void index_destroy(svs_index* idx) {
     (void)hipEventDestroy(t.e2);
   }
   (void)hipFree(idx->rows);
+  (void)hipFree(idx->row_scales);
   delete idx;
 }
 
@@ -272,10 +281,48 @@ int stage_queries_f16(const svs_index* idx, Ctx* c, const float* q, int nq, int 
   return SVS_OK;
 }
 
+// quantises nq f32 queries to e4m3 into c->q8 ([rows_alloc][ld] bytes, rows >= nq zero) with
+// scales c->q8s; want_f32 also fills c->q8f with the quantised values as f32
+int stage_queries_fp8(const svs_index* idx, Ctx* c, const float* q, int nq, int rows_alloc, bool want_f32, hipStream_t st) {
+  int rc;
+  if ((rc = grow_dev(&c->q8, &c->q8_cap, (size_t)rows_alloc * idx->ld)) != SVS_OK) return rc;
+  if ((rc = grow_dev(&c->q8s, &c->q8s_cap, (size_t)rows_alloc)) != SVS_OK) return rc;
+  if (want_f32 && (rc = grow_dev(&c->q8f, &c->q8f_cap, (size_t)rows_alloc * idx->ld)) != SVS_OK) return rc;
+  if (rows_alloc > nq) {
+    HIP_TRY(hipMemsetAsync(c->q8, 0, (size_t)rows_alloc * idx->ld, st));
+    HIP_TRY(hipMemsetAsync(c->q8s, 0, (size_t)rows_alloc * sizeof(float), st));
+  }
+  hipLaunchKernelGGL(quantize_rows_fp8_kernel, dim3((nq + 3) / 4), dim3(256), 0, st, q, (int64_t)nq, idx->d, (int64_t)idx->d,
+                     c->q8, idx->ld, c->q8s, want_f32 ? c->q8f : (float*)nullptr);
+  return SVS_OK;
+}
+
+template <int T>
+void launch_gemv_fp8(const svs_index* idx, Ctx* c, float* scores, hipStream_t st) {
+  constexpr int RPW = 64 / T;
+  int64_t waves = (idx->n + RPW - 1) / RPW;
+  int blocks = (int)std::min<int64_t>((waves + 3) / 4, (int64_t)idx->cu_count * 8);
+  hipLaunchKernelGGL((gemv_fp8_kernel<T>), dim3(blocks), dim3(256), 0, st, (const u32x4_t*)idx->rows, idx->row_scales,
+                     (const v4f*)c->q8f, c->q8s, scores, idx->n, idx->ld / 16);
+}
+
 // q: device, d floats (unpadded); scores: device, n floats
 int launch_scores(const svs_index* idx, Ctx* c, const float* q, float* scores, hipStream_t st) {
   const int variant = idx->variant.load();
   const bool q_aligned = (((uintptr_t)q) & 15) == 0;
+  if (idx->dtype == SVS_DTYPE_FP8) {
+    int rc = stage_queries_fp8(idx, c, q, 1, 1, true, st);
+    if (rc != SVS_OK) return rc;
+    const int ld16 = idx->ld / 16;
+    if (ld16 <= 1) launch_gemv_fp8<1>(idx, c, scores, st);
+    else if (ld16 <= 2) launch_gemv_fp8<2>(idx, c, scores, st);
+    else if (ld16 <= 4) launch_gemv_fp8<4>(idx, c, scores, st);
+    else if (ld16 <= 8) launch_gemv_fp8<8>(idx, c, scores, st);
+    else if (ld16 <= 16) launch_gemv_fp8<16>(idx, c, scores, st);
+    else if (ld16 <= 32) launch_gemv_fp8<32>(idx, c, scores, st);
+    else launch_gemv_fp8<64>(idx, c, scores, st);
+    return SVS_OK;
+  }
   if (idx->dtype == SVS_DTYPE_F16) {
     if (idx->ld == idx->d && idx->ld % 512 == 0 && q_aligned) {
       switch (idx->ld / 512) {
@@ -360,10 +407,12 @@ int launch_scores_q16(const svs_index* idx, Ctx* c, const float* q_dev, int nq_g
   return SVS_OK;
 }
 
-// ---- LDS-tiled MFMA GEMM, f16 corpus (gemm_f16_tiled.h) -----------------------
-bool f16_tiled_ok(const svs_index* idx) {
-  const int v = idx->variant.load();
-  return idx->dtype == SVS_DTYPE_F16 && idx->ld % TG_BK == 0 && v != 7;
+// ---- LDS-tiled MFMA GEMM, f16 / fp8 corpus (gemm_tiled.h) ----------------------
+bool tiled_ok(const svs_index* idx) {
+  if (idx->variant.load() == 7) return false;
+  if (idx->dtype == SVS_DTYPE_F16) return (idx->ld * 2) % TG_BKB == 0;
+  if (idx->dtype == SVS_DTYPE_FP8) return idx->ld % TG_BKB == 0;
+  return false;
 }
 
 struct FuseLaunch {   // non-null state: fused top-k epilogue, no score matrix
@@ -373,41 +422,50 @@ struct FuseLaunch {   // non-null state: fused top-k epilogue, no score matrix
   int thr_stride = 0;
 };
 
-template <int BN, bool FUSE>
-int launch_f16_tiled_bn(const svs_index* idx, Ctx* c, int64_t n_rows, int nq, float* scores, int64_t sstride,
-                        FuseLaunch fl, hipStream_t st) {
+template <int BN, bool FUSE, int EB>
+int launch_tiled_bn(const svs_index* idx, Ctx* c, int64_t n_rows, int nq, float* scores, int64_t sstride,
+                    FuseLaunch fl, hipStream_t st) {
   static std::once_flag once;
   const size_t lds = (size_t)(3 * TG_BM * 8 + 3 * BN * 8) * sizeof(u32x4);
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute((const void*)gemm_f16_tiled_kernel<BN, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void*)gemm_tiled_kernel<BN, FUSE, EB>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)((3 * TG_BM * 8 + 3 * BN * 8) * sizeof(u32x4)));
   });
   const unsigned gx = (unsigned)((n_rows + TG_BM - 1) / TG_BM), gy = (unsigned)((nq + BN - 1) / BN);
-  hipLaunchKernelGGL((gemm_f16_tiled_kernel<BN, FUSE>), dim3(gx, gy), dim3(TG_WAVES * 64), lds, st,
-                     (const _Float16*)idx->rows, (const _Float16*)c->qh, scores, n_rows, idx->ld, sstride, nq,
-                     fl.state, (int)SCR_WORDS, fl.cand, (uint32_t)CAND_CAP, fl.thr, fl.thr_stride);
+  const uint8_t* Q = EB == 2 ? (const uint8_t*)c->qh : (const uint8_t*)c->q8;
+  hipLaunchKernelGGL((gemm_tiled_kernel<BN, FUSE, EB>), dim3(gx, gy), dim3(TG_WAVES * 64), lds, st,
+                     (const uint8_t*)idx->rows, Q, scores, n_rows, (int64_t)idx->ld * EB, sstride, nq,
+                     fl.state, (int)SCR_WORDS, fl.cand, (uint32_t)CAND_CAP, fl.thr, fl.thr_stride,
+                     (const float*)idx->row_scales, (const float*)c->q8s);
   return SVS_OK;
 }
 
-// rows [0, n_rows) of the corpus; restage == false reuses the half queries already in c->qh
-int launch_scores_f16_tiled(const svs_index* idx, Ctx* c, const float* q_dev, int64_t n_rows, int nq, float* scores,
-                            int64_t sstride, FuseLaunch fl, hipStream_t st, bool restage = true) {
-  const int bn = nq <= 32 ? 32 : (nq <= 64 ? 64 : (nq <= 128 ? 128 : 256));
-  const int nq_pad = (nq + bn - 1) / bn * bn;
-  if (restage) {
-    int rc = stage_queries_f16(idx, c, q_dev, nq, nq_pad, st);
-    if (rc != SVS_OK) return rc;
-  }
+template <int EB>
+int launch_tiled_eb(const svs_index* idx, Ctx* c, int64_t n_rows, int nq, int bn, float* scores, int64_t sstride,
+                    FuseLaunch fl, hipStream_t st) {
   const bool f = fl.state != nullptr;
   switch (bn) {
-    case 32: return f ? launch_f16_tiled_bn<32, true>(idx, c, n_rows, nq, scores, sstride, fl, st) : launch_f16_tiled_bn<32, false>(idx, c, n_rows, nq, scores, sstride, fl, st);
-    case 64: return f ? launch_f16_tiled_bn<64, true>(idx, c, n_rows, nq, scores, sstride, fl, st) : launch_f16_tiled_bn<64, false>(idx, c, n_rows, nq, scores, sstride, fl, st);
-    case 128: return f ? launch_f16_tiled_bn<128, true>(idx, c, n_rows, nq, scores, sstride, fl, st) : launch_f16_tiled_bn<128, false>(idx, c, n_rows, nq, scores, sstride, fl, st);
-    default: return f ? launch_f16_tiled_bn<256, true>(idx, c, n_rows, nq, scores, sstride, fl, st) : launch_f16_tiled_bn<256, false>(idx, c, n_rows, nq, scores, sstride, fl, st);
+    case 32: return f ? launch_tiled_bn<32, true, EB>(idx, c, n_rows, nq, scores, sstride, fl, st) : launch_tiled_bn<32, false, EB>(idx, c, n_rows, nq, scores, sstride, fl, st);
+    case 64: return f ? launch_tiled_bn<64, true, EB>(idx, c, n_rows, nq, scores, sstride, fl, st) : launch_tiled_bn<64, false, EB>(idx, c, n_rows, nq, scores, sstride, fl, st);
+    case 128: return f ? launch_tiled_bn<128, true, EB>(idx, c, n_rows, nq, scores, sstride, fl, st) : launch_tiled_bn<128, false, EB>(idx, c, n_rows, nq, scores, sstride, fl, st);
+    default: return f ? launch_tiled_bn<256, true, EB>(idx, c, n_rows, nq, scores, sstride, fl, st) : launch_tiled_bn<256, false, EB>(idx, c, n_rows, nq, scores, sstride, fl, st);
   }
 }
 
-// ---- whole search on a stream; all pointers are device pointers --------------
+// rows [0, n_rows) of the corpus; restage == false reuses the quantised queries already staged in the context
+int launch_scores_tiled(const svs_index* idx, Ctx* c, const float* q_dev, int64_t n_rows, int nq, float* scores,
+                        int64_t sstride, FuseLaunch fl, hipStream_t st, bool restage = true) {
+  const int bn = nq <= 32 ? 32 : (nq <= 64 ? 64 : (nq <= 128 ? 128 : 256));
+  const int nq_pad = (nq + bn - 1) / bn * bn;
+  if (restage) {
+    int rc = idx->dtype == SVS_DTYPE_F16 ? stage_queries_f16(idx, c, q_dev, nq, nq_pad, st)
+                                         : stage_queries_fp8(idx, c, q_dev, nq, nq_pad, false, st);
+    if (rc != SVS_OK) return rc;
+  }
+  return idx->dtype == SVS_DTYPE_F16 ? launch_tiled_eb<2>(idx, c, n_rows, nq, bn, scores, sstride, fl, st)
+                                     : launch_tiled_eb<1>(idx, c, n_rows, nq, bn, scores, sstride, fl, st);
+}
+
 // Top-k stage over a materialised score matrix scores[nq][sstride] with n_eff rows.
 int run_select(svs_index* idx, Ctx* c, const float* scores, int64_t n_eff, int64_t sstride, int nq, int k,
                int count, float* out_s, int64_t* out_r, hipStream_t st) {
@@ -454,7 +512,7 @@ int enqueue_search(svs_index* idx, Ctx* c, const float* q_dev, int nq, int k, in
   const bool path_a = k > 0 && n > SORT_CAP && count <= SEL_KMAX;
   // Fused top-k epilogue (no score matrix): batched f16 GEMM only; a query whose
   // candidate list overflows comes back marked and is re-run by the caller.
-  const bool fused = allow_fused && path_a && nq >= 64 && n >= 8 * FUSE_PREFIX_ROWS && f16_tiled_ok(idx) &&
+  const bool fused = allow_fused && path_a && nq >= 64 && n >= 8 * FUSE_PREFIX_ROWS && tiled_ok(idx) &&
                      idx->variant.load() != 6;
   const int64_t n_mat = fused ? FUSE_PREFIX_ROWS : n;        // rows of the materialised score matrix
   const int64_t sstride = (n_mat + 3) & ~(int64_t)3;         // float4-aligned score vectors
@@ -483,11 +541,11 @@ int enqueue_search(svs_index* idx, Ctx* c, const float* q_dev, int nq, int k, in
     // 1. thresholds: exact k-th best of the first FUSE_PREFIX_ROWS rows, per query
     if ((rc = grow_dev(&c->pref_s, &c->pref_s_cap, (size_t)nq * count)) != SVS_OK) return rc;
     if ((rc = grow_dev(&c->pref_r, &c->pref_r_cap, (size_t)nq * count)) != SVS_OK) return rc;
-    if ((rc = launch_scores_f16_tiled(idx, c, q_dev, n_mat, nq, c->scores, sstride, FuseLaunch{}, st)) != SVS_OK) return rc;
+    if ((rc = launch_scores_tiled(idx, c, q_dev, n_mat, nq, c->scores, sstride, FuseLaunch{}, st)) != SVS_OK) return rc;
     if ((rc = run_select(idx, c, c->scores, n_mat, sstride, nq, count, count, c->pref_s, c->pref_r, st)) != SVS_OK) return rc;
     // 2. the whole corpus, keeping only scores >= threshold
     FuseLaunch fl{c->hist, c->cand, c->pref_s + (count - 1), count};
-    if ((rc = launch_scores_f16_tiled(idx, c, q_dev, n, nq, nullptr, 0, fl, st, false)) != SVS_OK) return rc;
+    if ((rc = launch_scores_tiled(idx, c, q_dev, n, nq, nullptr, 0, fl, st, false)) != SVS_OK) return rc;
     if (timed) HIP_TRY(hipEventRecord(ev.e1, st));
     hipLaunchKernelGGL(select_final_kernel, dim3(nq), dim3(FINAL_THREADS), 0, st, (const float*)nullptr, n, (int64_t)0, k, count, 3,
                        c->hist, c->cand, idx->row_offset, out_s, out_r);
@@ -498,8 +556,8 @@ int enqueue_search(svs_index* idx, Ctx* c, const float* q_dev, int nq, int k, in
                                c->scores + (size_t)q0 * sstride, sstride, st);
         if (rc != SVS_OK) return rc;
       }
-    } else if (nq >= 2 && f16_tiled_ok(idx)) {
-      if ((rc = launch_scores_f16_tiled(idx, c, q_dev, n, nq, c->scores, sstride, FuseLaunch{}, st)) != SVS_OK) return rc;
+    } else if (nq >= 2 && tiled_ok(idx)) {
+      if ((rc = launch_scores_tiled(idx, c, q_dev, n, nq, c->scores, sstride, FuseLaunch{}, st)) != SVS_OK) return rc;
     } else {
       for (int qi = 0; qi < nq; ++qi) {
         rc = launch_scores(idx, c, q_dev + (size_t)qi * idx->d, c->scores + (size_t)qi * sstride, st);
@@ -533,8 +591,8 @@ int create_common(int64_t n, int32_t d, int32_t store_dtype, int32_t device, int
   if (!out) return fail(SVS_ERR_INVALID, "null out");
   *out = nullptr;
   if (n < 0 || d < 0) return fail(SVS_ERR_INVALID, "negative shape (%lld, %d)", (long long)n, d);
-  if (store_dtype != SVS_DTYPE_F32 && store_dtype != SVS_DTYPE_F16)
-    return fail(SVS_ERR_UNSUPPORTED, "store dtype %d not implemented yet", store_dtype);
+  if (store_dtype != SVS_DTYPE_F32 && store_dtype != SVS_DTYPE_F16 && store_dtype != SVS_DTYPE_FP8)
+    return fail(SVS_ERR_UNSUPPORTED, "unknown store dtype %d", store_dtype);
   if (n > 0xffffffffll) return fail(SVS_ERR_INVALID, "at most 2^32 rows per handle; shard the corpus");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(SVS_ERR_DEVICE, "no HIP device visible");
@@ -546,16 +604,26 @@ int create_common(int64_t n, int32_t d, int32_t store_dtype, int32_t device, int
   idx->n = n;
   idx->d = d;
   idx->dtype = store_dtype;
-  idx->ld = store_dtype == SVS_DTYPE_F16 ? (d + 7) / 8 * 8 : (d + 3) / 4 * 4;  // 16-byte aligned rows
+  // 16-byte aligned rows: 4 floats, 8 halves or 16 fp8 bytes
+  idx->ld = store_dtype == SVS_DTYPE_F16 ? (d + 7) / 8 * 8 : (store_dtype == SVS_DTYPE_FP8 ? (d + 15) / 16 * 16 : (d + 3) / 4 * 4);
   idx->row_offset = row_offset;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) idx->cu_count = prop.multiProcessorCount;
-  idx->bytes = (size_t)n * (size_t)idx->ld * (store_dtype == SVS_DTYPE_F16 ? 2 : 4);
+  idx->bytes = (size_t)n * (size_t)idx->ld * (store_dtype == SVS_DTYPE_F16 ? 2 : (store_dtype == SVS_DTYPE_FP8 ? 1 : 4));
   if (idx->bytes) {
     hipError_t e = hipMalloc(&idx->rows, idx->bytes);
     if (e != hipSuccess) {
       delete idx;
       return fail(e == hipErrorOutOfMemory ? SVS_ERR_NOMEM : SVS_ERR_DEVICE, "hipMalloc(%zu): %s", idx->bytes, hipGetErrorString(e));
+    }
+    if (store_dtype == SVS_DTYPE_FP8) {
+      e = hipMalloc((void**)&idx->row_scales, (size_t)n * sizeof(float));
+      if (e != hipSuccess) {
+        (void)hipFree(idx->rows);
+        delete idx;
+        return fail(SVS_ERR_NOMEM, "hipMalloc(row scales): %s", hipGetErrorString(e));
+      }
+      idx->bytes += (size_t)n * sizeof(float);
     }
   }
   *made = idx;
@@ -588,7 +656,7 @@ int32_t svs_index_create(const float* host_rows, int64_t n, int32_t d, int32_t s
     // pinned double-buffered staging: host memcpy of chunk i+1 overlaps the DMA of chunk i.
     // f32 corpus: the DMA writes the padded HBM layout directly (2D copy).
     // f16 corpus: the DMA lands in a device staging buffer and a kernel rounds it to half.
-    const bool f16 = idx->dtype == SVS_DTYPE_F16;
+    const bool f16 = idx->dtype != SVS_DTYPE_F32;   // f16 and fp8: convert on the device
     const size_t row_b = (size_t)d * sizeof(float);
     const size_t chunk_rows = std::max<size_t>(1, (32u << 20) / row_b);
     void* pin[2] = {nullptr, nullptr};
@@ -611,8 +679,13 @@ int32_t svs_index_create(const float* host_rows, int64_t n, int32_t d, int32_t s
       if (f16) {
         e = hipMemcpyAsync(dstage[b], pin[b], rows * row_b, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) {
-          hipLaunchKernelGGL(convert_rows_f16_kernel, dim3(2048), dim3(256), 0, st, (const float*)dstage[b],
-                             (int64_t)rows, d, (int64_t)d, (_Float16*)idx->rows + r0 * (size_t)idx->ld, idx->ld);
+          if (idx->dtype == SVS_DTYPE_F16)
+            hipLaunchKernelGGL(convert_rows_f16_kernel, dim3(2048), dim3(256), 0, st, (const float*)dstage[b],
+                               (int64_t)rows, d, (int64_t)d, (_Float16*)idx->rows + r0 * (size_t)idx->ld, idx->ld);
+          else
+            hipLaunchKernelGGL(quantize_rows_fp8_kernel, dim3(2048), dim3(256), 0, st, (const float*)dstage[b],
+                               (int64_t)rows, d, (int64_t)d, (uint8_t*)idx->rows + r0 * (size_t)idx->ld, idx->ld,
+                               idx->row_scales + r0, (float*)nullptr);
           e = hipGetLastError();
         }
       } else if (idx->ld == d) {
@@ -654,6 +727,10 @@ int32_t svs_index_create_from_device(const float* dev_rows, int64_t n, int32_t d
     if (idx->dtype == SVS_DTYPE_F16) {
       hipLaunchKernelGGL(convert_rows_f16_kernel, dim3(4096), dim3(256), 0, 0, dev_rows, n, d, src_ld,
                          (_Float16*)idx->rows, idx->ld);
+      e = hipGetLastError();
+    } else if (idx->dtype == SVS_DTYPE_FP8) {
+      hipLaunchKernelGGL(quantize_rows_fp8_kernel, dim3(4096), dim3(256), 0, 0, dev_rows, n, d, src_ld,
+                         (uint8_t*)idx->rows, idx->ld, idx->row_scales, (float*)nullptr);
       e = hipGetLastError();
     } else {
       if (idx->ld != d) e = hipMemset(idx->rows, 0, idx->bytes);
@@ -795,6 +872,47 @@ int32_t svs_index_scores(svs_index* idx, const float* query, int32_t d, float* o
   HIP_TRY(hipMemcpyAsync(out_scores, c->scores, (size_t)idx->n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return SVS_OK;
+}
+
+int32_t svs_index_debug_dequant(svs_index* idx, int64_t row0, int64_t nrows, float* out) {
+  if (!idx || !out) return fail(SVS_ERR_INVALID, "null argument");
+  if (row0 < 0 || nrows < 0 || row0 + nrows > idx->n) return fail(SVS_ERR_INVALID, "row range out of bounds");
+  if (nrows == 0 || idx->d == 0) return SVS_OK;
+  HIP_TRY(hipSetDevice(idx->device));
+  const size_t cnt = (size_t)nrows * idx->d;
+  if (idx->dtype == SVS_DTYPE_F32) {
+    HIP_TRY(hipMemcpy2D(out, (size_t)idx->d * sizeof(float), (const float*)idx->rows + row0 * idx->ld,
+                        (size_t)idx->ld * sizeof(float), (size_t)idx->d * sizeof(float), (size_t)nrows, hipMemcpyDeviceToHost));
+    return SVS_OK;
+  }
+  float* tmp = nullptr;
+  HIP_TRY(hipMalloc((void**)&tmp, cnt * sizeof(float)));
+  if (idx->dtype == SVS_DTYPE_F16)
+    hipLaunchKernelGGL(dequant_rows_f16_kernel, dim3(2048), dim3(256), 0, 0, (const _Float16*)idx->rows, row0, nrows, idx->d, idx->ld, tmp);
+  else
+    hipLaunchKernelGGL(dequant_rows_fp8_kernel, dim3(2048), dim3(256), 0, 0, (const uint8_t*)idx->rows, idx->row_scales, row0, nrows,
+                       idx->d, idx->ld, tmp);
+  hipError_t e = hipMemcpy(out, tmp, cnt * sizeof(float), hipMemcpyDeviceToHost);
+  (void)hipFree(tmp);
+  if (e != hipSuccess) return fail(SVS_ERR_DEVICE, "dequant read-back: %s", hipGetErrorString(e));
+  return SVS_OK;
+}
+
+int32_t svs_index_debug_query(svs_index* idx, const float* query, int32_t d, float* out) {
+  if (!idx || !query || !out) return fail(SVS_ERR_INVALID, "null argument");
+  if (d != idx->d) return fail(SVS_ERR_SHAPE, "query dim %d != index dim %d", d, idx->d);
+  if (idx->dtype == SVS_DTYPE_F32 || d == 0) {
+    memcpy(out, query, (size_t)d * sizeof(float));
+    return SVS_OK;
+  }
+  // build a one-row index of the same dtype from the query and read it back: the
+  // row path and the query path share their rounding / quantisation kernels
+  svs_index* tmp = nullptr;
+  int rc = svs_index_create(query, 1, d, idx->dtype, idx->device, 0, &tmp);
+  if (rc != SVS_OK) return rc;
+  rc = svs_index_debug_dequant(tmp, 0, 1, out);
+  svs_index_release(tmp);
+  return rc;
 }
 
 int32_t svs_index_set_timing(svs_index* idx, int32_t enable) {

@@ -18,8 +18,9 @@ from . import _native
 
 
 # HBM element type of the corpus.  "f32" is the reference layout; "f16" rounds
-# rows (and queries) to half, f32 accumulate -- BASELINE.json configs[2]/[3].
-_DTYPES = {"f32": _native.DTYPE_F32, "f16": _native.DTYPE_F16}
+# rows (and queries) to half, f32 accumulate -- BASELINE.json configs[2]/[3];
+# "fp8" stores OCP e4m3 with one f32 scale per row -- configs[4].
+_DTYPES = {"f32": _native.DTYPE_F32, "f16": _native.DTYPE_F16, "fp8": _native.DTYPE_FP8}
 
 
 class DeviceIndex:
@@ -174,6 +175,24 @@ class DeviceIndex:
         finally:
             self._lib.svs_index_release(h)
         return count.value
+
+    # -- parity support -----------------------------------------------------
+    def stored_rows(self, row0: int = 0, nrows: Optional[int] = None) -> np.ndarray:
+        """Rows exactly as held in HBM, dequantised to f32 (the corpus the oracle
+        must be run on for the f16 / fp8 dtypes)."""
+        nrows = self.n - row0 if nrows is None else nrows
+        out = np.empty((nrows, self.d), dtype=np.float32)
+        _native.check(self._lib.svs_index_debug_dequant(self._handle(), int(row0), int(nrows),
+                                                        out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def stored_query(self, query_vec: np.ndarray) -> np.ndarray:
+        """The query as this index's kernels see it (rounded / quantised)."""
+        q = np.ascontiguousarray(query_vec, dtype=np.float32)
+        out = np.empty_like(q)
+        _native.check(self._lib.svs_index_debug_query(self._handle(), q.ctypes.data_as(C.c_void_p), q.shape[0],
+                                                      out.ctypes.data_as(C.c_void_p)))
+        return out
 
     # -- measurement ------------------------------------------------------
     def set_timing(self, enable: bool) -> None:

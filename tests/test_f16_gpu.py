@@ -30,6 +30,9 @@ def test_f16_single_query(gpu, n, d, k):
                            oracle.cpu_scores_f64(md, qd), label=f"f16 {n}x{d}")
     sc = idx.scores(qs[0])
     assert np.max(np.abs(sc - oracle.cpu_scores_f64(md, _deq(qs[0])))) < 5e-7
+    # what the index holds IS numpy's half rounding of the corpus / query
+    assert np.array_equal(idx.stored_rows(0, min(n, 64)), md[:64])
+    assert np.array_equal(idx.stored_query(qs[0]), _deq(qs[0]))
     idx.release()
 
 
