@@ -101,6 +101,72 @@ __device__ __forceinline__ float dot16_fp8(u32x4_t a, const v4f* q, float acc) {
   return acc;
 }
 
+// ---- single query, hot kernel: one-shot grid, R rows per wave (gemv_f32.h geometry)
+// A row of ld8 = NSTEP * 64 * LB bytes is NSTEP wave-wide loads of LB (16 or 8)
+// bytes per lane; the quantised query sits in NSTEP * LB f32 registers per lane.
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+
+template <int LB> struct Fp8Chunk;
+template <> struct Fp8Chunk<16> { typedef u32x4_t type; };
+template <> struct Fp8Chunk<8> { typedef u32x2_t type; };
+
+template <int NSTEP, int LB, int R, int WPB>
+__global__ __launch_bounds__(WPB * 64) void gemv_fp8_oneshot_kernel(
+    const uint8_t* __restrict__ M, const float* __restrict__ row_scales, const float* __restrict__ qf,
+    const float* __restrict__ q_scale, float* __restrict__ scores, int64_t n) {
+  typedef typename Fp8Chunk<LB>::type chunk_t;
+  constexpr int NW = LB / 4;               // 32-bit words per lane per load
+  constexpr int64_t LDB = (int64_t)NSTEP * 64 * LB;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t row0 = ((int64_t)blockIdx.x * WPB + wave) * R;
+  if (row0 >= n) return;
+  chunk_t buf[R][NSTEP];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    int64_t row = row0 + r;
+    row = row < n ? row : n - 1;
+    const chunk_t* p = (const chunk_t*)(M + row * LDB) + lane;
+#pragma unroll
+    for (int j = 0; j < NSTEP; ++j) buf[r][j] = __builtin_nontemporal_load(p + j * 64);
+  }
+  float qv[NSTEP][LB];
+#pragma unroll
+  for (int j = 0; j < NSTEP; ++j) {
+    const v4f* qp = (const v4f*)(qf + (int64_t)(j * 64 + lane) * LB);
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const v4f t = qp[w];
+      qv[j][4 * w + 0] = t.x; qv[j][4 * w + 1] = t.y; qv[j][4 * w + 2] = t.z; qv[j][4 * w + 3] = t.w;
+    }
+  }
+  const float sq = q_scale[0];
+  float out = 0.f;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NSTEP; ++j) {
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        float v[4];
+        unpack_fp8x4(buf[r][j][w], v);
+        float& acc = (w & 1) ? s1 : s0;
+        acc = fmaf(v[0], qv[j][4 * w + 0], acc);
+        acc = fmaf(v[1], qv[j][4 * w + 1], acc);
+        acc = fmaf(v[2], qv[j][4 * w + 2], acc);
+        acc = fmaf(v[3], qv[j][4 * w + 3], acc);
+      }
+    }
+    int64_t row = row0 + r;
+    row = row < n ? row : n - 1;
+    const float v = wave_sum(s0 + s1) * row_scales[row] * sq;
+    out = lane == r ? v : out;
+  }
+  const int64_t row = row0 + lane;
+  if (lane < R && row < n) scores[row] = out;
+}
+
 // ---- single query: T lanes per row, 64/T rows per wave step --------------------
 // M: e4m3 rows (ld8 bytes, multiple of 16); qf: the quantised query as f32 (ld8
 // floats, zero padded); score = row scale * query scale * dot.

@@ -313,6 +313,24 @@ int launch_scores(const svs_index* idx, Ctx* c, const float* q, float* scores, h
   if (idx->dtype == SVS_DTYPE_FP8) {
     int rc = stage_queries_fp8(idx, c, q, 1, 1, true, st);
     if (rc != SVS_OK) return rc;
+    // hot geometries: one-shot grid, 16 waves, nontemporal row loads (as gemv_f32.h)
+#define SVS_FP8_HOT(NSTEP, LB, R)                                                                               \
+  do {                                                                                                          \
+    const int64_t blocks = (idx->n + (R) * 16 - 1) / ((R) * 16);                                                \
+    hipLaunchKernelGGL((gemv_fp8_oneshot_kernel<NSTEP, LB, R, 16>), dim3((unsigned)blocks), dim3(16 * 64), 0, st, \
+                       (const uint8_t*)idx->rows, idx->row_scales, (const float*)c->q8f, c->q8s, scores, idx->n);   \
+    return SVS_OK;                                                                                              \
+  } while (0)
+    switch (idx->ld) {
+      case 1024: SVS_FP8_HOT(1, 16, 4);
+      case 2048: SVS_FP8_HOT(2, 16, 2);
+      case 3072: SVS_FP8_HOT(3, 16, 2);
+      case 4096: SVS_FP8_HOT(4, 16, 1);
+      case 512: SVS_FP8_HOT(1, 8, 4);
+      case 1536: SVS_FP8_HOT(3, 8, 2);
+      default: break;
+    }
+#undef SVS_FP8_HOT
     const int ld16 = idx->ld / 16;
     if (ld16 <= 1) launch_gemv_fp8<1>(idx, c, scores, st);
     else if (ld16 <= 2) launch_gemv_fp8<2>(idx, c, scores, st);
@@ -503,7 +521,13 @@ int run_select(svs_index* idx, Ctx* c, const float* scores, int64_t n_eff, int64
   return SVS_OK;
 }
 
-constexpr int64_t FUSE_PREFIX_ROWS = 16384;  // rows whose exact k-th best seeds the fused epilogue's thresholds
+// rows whose exact k-th best seeds the fused epilogue's thresholds: about k * n / prefix
+// candidates per query survive, so the prefix grows with n (n/64 -> ~64 k survivors)
+constexpr int64_t FUSE_PREFIX_MIN = 16384;
+inline int64_t fuse_prefix_rows(int64_t n) {
+  const int64_t p = std::max<int64_t>(FUSE_PREFIX_MIN, n / 64);
+  return (p + 127) / 128 * 128;
+}
 
 int enqueue_search(svs_index* idx, Ctx* c, const float* q_dev, int nq, int k, int count,
                    float* out_s, int64_t* out_r, hipStream_t st, bool allow_fused = false) {
@@ -512,9 +536,9 @@ int enqueue_search(svs_index* idx, Ctx* c, const float* q_dev, int nq, int k, in
   const bool path_a = k > 0 && n > SORT_CAP && count <= SEL_KMAX;
   // Fused top-k epilogue (no score matrix): batched f16 GEMM only; a query whose
   // candidate list overflows comes back marked and is re-run by the caller.
-  const bool fused = allow_fused && path_a && nq >= 64 && n >= 8 * FUSE_PREFIX_ROWS && tiled_ok(idx) &&
-                     idx->variant.load() != 6;
-  const int64_t n_mat = fused ? FUSE_PREFIX_ROWS : n;        // rows of the materialised score matrix
+  const bool fused = allow_fused && path_a && nq >= 64 && n >= 8 * FUSE_PREFIX_MIN && tiled_ok(idx) &&
+                     count <= 256 && idx->variant.load() != 6;
+  const int64_t n_mat = fused ? fuse_prefix_rows(n) : n;     // rows of the materialised score matrix
   const int64_t sstride = (n_mat + 3) & ~(int64_t)3;         // float4-aligned score vectors
   if ((rc = grow_dev(&c->scores, &c->scores_cap, (size_t)nq * (size_t)sstride)) != SVS_OK) return rc;
   if (path_a && (size_t)nq > c->hist_cap) {
