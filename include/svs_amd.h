@@ -131,6 +131,15 @@ int32_t svs_index_search_device(svs_index* idx, const float* dev_queries, int32_
  * (src/svs/kb.py:1623) for callers that want it and for parity tests. */
 int32_t svs_index_scores(svs_index* idx, const float* query, int32_t d, float* out_scores);
 
+/* ---- pairwise: replaces np.dot(M, M.T) + get_top_pairs of
+ *      document_top_pairwise_scores, src/svs/kb.py:1642-1671, src/svs/util.py:206-233 --
+ * The k best-scoring row PAIRS (i < j; diagonal and lower triangle ignored), ordered
+ * (score desc, then i desc, then j desc -- the reference's flat upper-triangle index,
+ * descending).  count = min(max(k,0), n(n-1)/2).  The n x n score matrix is
+ * materialised in HBM like the reference materialises it in RAM; n*n <= 2^32. */
+int32_t svs_index_top_pairs(svs_index* idx, int32_t k, float* out_scores, int64_t* out_i, int64_t* out_j,
+                            int32_t* out_count);
+
 /* ---- parity support (tests): what the index really holds -------------------- */
 /* Rows [row0, row0 + nrows) exactly as stored, dequantised to f32 (nrows x d,
  * C-contiguous, host).  f32: the rows; f16: half-rounded; fp8: e4m3 * row scale. */

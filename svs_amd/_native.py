@@ -59,6 +59,7 @@ SIGNATURES = {
     "svs_index_search": (C.c_int32, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.POINTER(C.c_int32)]),
     "svs_index_search_device": (C.c_int32, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.POINTER(C.c_int32), _P]),
     "svs_index_scores": (C.c_int32, [_P, _P, C.c_int32, _P]),
+    "svs_index_top_pairs": (C.c_int32, [_P, C.c_int32, _P, _P, _P, C.POINTER(C.c_int32)]),
     "svs_index_debug_dequant": (C.c_int32, [_P, C.c_int64, C.c_int64, _P]),
     "svs_index_debug_query": (C.c_int32, [_P, _P, C.c_int32, _P]),
     "svs_index_set_timing": (C.c_int32, [_P, C.c_int32]),

@@ -373,6 +373,20 @@ __global__ __launch_bounds__(FINAL_THREADS) void select_final_kernel(
   emit_topk(S, count, k_out, row_offset, os, orow);
 }
 
+// ---- pairwise path: keep the strict upper triangle of an N x N score matrix ----
+// S is [n][np] (np = padded row stride): entry (i, j) survives iff i < j < n; all
+// others become -inf, so the flattened matrix is one score vector whose top-k are
+// the reference's top pairs (src/svs/util.py:206-233: np.triu_indices(k=1), then
+// get_top_k; flat index order == (i, j) lexicographic, ties largest first).
+__global__ void mask_upper_triangle_kernel(float* __restrict__ S, int64_t n, int64_t np) {
+  const int64_t total = n * np;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t i = t / np, j = t - i * np;
+    if (j <= i || j >= n) S[t] = -__builtin_inff();
+  }
+}
+
 // ---- path B: global bitonic sort of all keys --------------------------------
 // keys is [nq][npad], npad a power of two >= max(n, 2).
 __global__ void keys_build_kernel(const float* __restrict__ scores, int64_t n,

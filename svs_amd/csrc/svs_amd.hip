@@ -486,11 +486,11 @@ int launch_scores_tiled(const svs_index* idx, Ctx* c, const float* q_dev, int64_
 
 // Top-k stage over a materialised score matrix scores[nq][sstride] with n_eff rows.
 int run_select(svs_index* idx, Ctx* c, const float* scores, int64_t n_eff, int64_t sstride, int nq, int k,
-               int count, float* out_s, int64_t* out_r, hipStream_t st) {
+               int count, float* out_s, int64_t* out_r, hipStream_t st, int64_t row_offset) {
   int rc;
   if (n_eff <= SORT_CAP) {
     hipLaunchKernelGGL(select_final_kernel, dim3(nq), dim3(FINAL_THREADS), 0, st, scores, n_eff, sstride, k, count, 1,
-                       (uint32_t*)nullptr, (const uint64_t*)nullptr, idx->row_offset, out_s, out_r);
+                       (uint32_t*)nullptr, (const uint64_t*)nullptr, row_offset, out_s, out_r);
   } else if (count <= SEL_KMAX) {
     const int64_t per_block = (int64_t)FA_THREADS * SEL_VPT * 4;
     const unsigned blocks = (unsigned)((n_eff + per_block - 1) / per_block);
@@ -498,7 +498,7 @@ int run_select(svs_index* idx, Ctx* c, const float* scores, int64_t n_eff, int64
     hipLaunchKernelGGL(select_window_filter_kernel, dim3(blocks, nq), dim3(FA_THREADS), 0, st, scores, n_eff, sstride,
                        (uint32_t)count, c->hist, c->cand);
     hipLaunchKernelGGL(select_final_kernel, dim3(nq), dim3(FINAL_THREADS), 0, st, scores, n_eff, sstride, k, count, 0,
-                       c->hist, c->cand, idx->row_offset, out_s, out_r);
+                       c->hist, c->cand, row_offset, out_s, out_r);
   } else {
     int64_t npad;
     next_pow2_i64(n_eff, &npad);
@@ -516,13 +516,32 @@ int run_select(svs_index* idx, Ctx* c, const float* scores, int64_t n_eff, int64
     }
     int ge = std::min((k + 255) / 256, 1024);
     hipLaunchKernelGGL(keys_emit_kernel, dim3(ge, nq), dim3(256), 0, st, c->keys, npad, k, count,
-                       idx->row_offset, out_s, out_r);
+                       row_offset, out_s, out_r);
   }
   return SVS_OK;
 }
 
 // rows whose exact k-th best seeds the fused epilogue's thresholds: about k * n / prefix
 // candidates per query survive, so the prefix grows with n (n/64 -> ~64 k survivors)
+// Materialised scores of nq queries: scores[q][sstride] (the non-fused score stage).
+int launch_scores_any(svs_index* idx, Ctx* c, const float* q_dev, int nq, float* scores, int64_t sstride, hipStream_t st) {
+  int rc;
+  if (nq >= 2 && batch_kernel_ok(idx)) {
+    for (int q0 = 0; q0 < nq; q0 += GQ) {
+      rc = launch_scores_q16(idx, c, q_dev + (size_t)q0 * idx->d, std::min(GQ, nq - q0), scores + (size_t)q0 * sstride, sstride, st);
+      if (rc != SVS_OK) return rc;
+    }
+  } else if (nq >= 2 && tiled_ok(idx)) {
+    if ((rc = launch_scores_tiled(idx, c, q_dev, idx->n, nq, scores, sstride, FuseLaunch{}, st)) != SVS_OK) return rc;
+  } else {
+    for (int qi = 0; qi < nq; ++qi) {
+      rc = launch_scores(idx, c, q_dev + (size_t)qi * idx->d, scores + (size_t)qi * sstride, st);
+      if (rc != SVS_OK) return rc;
+    }
+  }
+  return SVS_OK;
+}
+
 constexpr int64_t FUSE_PREFIX_MIN = 16384;
 inline int64_t fuse_prefix_rows(int64_t n) {
   const int64_t p = std::max<int64_t>(FUSE_PREFIX_MIN, n / 64);
@@ -566,7 +585,7 @@ int enqueue_search(svs_index* idx, Ctx* c, const float* q_dev, int nq, int k, in
     if ((rc = grow_dev(&c->pref_s, &c->pref_s_cap, (size_t)nq * count)) != SVS_OK) return rc;
     if ((rc = grow_dev(&c->pref_r, &c->pref_r_cap, (size_t)nq * count)) != SVS_OK) return rc;
     if ((rc = launch_scores_tiled(idx, c, q_dev, n_mat, nq, c->scores, sstride, FuseLaunch{}, st)) != SVS_OK) return rc;
-    if ((rc = run_select(idx, c, c->scores, n_mat, sstride, nq, count, count, c->pref_s, c->pref_r, st)) != SVS_OK) return rc;
+    if ((rc = run_select(idx, c, c->scores, n_mat, sstride, nq, count, count, c->pref_s, c->pref_r, st, idx->row_offset)) != SVS_OK) return rc;
     // 2. the whole corpus, keeping only scores >= threshold
     FuseLaunch fl{c->hist, c->cand, c->pref_s + (count - 1), count};
     if ((rc = launch_scores_tiled(idx, c, q_dev, n, nq, nullptr, 0, fl, st, false)) != SVS_OK) return rc;
@@ -574,22 +593,9 @@ int enqueue_search(svs_index* idx, Ctx* c, const float* q_dev, int nq, int k, in
     hipLaunchKernelGGL(select_final_kernel, dim3(nq), dim3(FINAL_THREADS), 0, st, (const float*)nullptr, n, (int64_t)0, k, count, 3,
                        c->hist, c->cand, idx->row_offset, out_s, out_r);
   } else {
-    if (nq >= 2 && batch_kernel_ok(idx)) {
-      for (int q0 = 0; q0 < nq; q0 += GQ) {
-        rc = launch_scores_q16(idx, c, q_dev + (size_t)q0 * idx->d, std::min(GQ, nq - q0),
-                               c->scores + (size_t)q0 * sstride, sstride, st);
-        if (rc != SVS_OK) return rc;
-      }
-    } else if (nq >= 2 && tiled_ok(idx)) {
-      if ((rc = launch_scores_tiled(idx, c, q_dev, n, nq, c->scores, sstride, FuseLaunch{}, st)) != SVS_OK) return rc;
-    } else {
-      for (int qi = 0; qi < nq; ++qi) {
-        rc = launch_scores(idx, c, q_dev + (size_t)qi * idx->d, c->scores + (size_t)qi * sstride, st);
-        if (rc != SVS_OK) return rc;
-      }
-    }
+    if ((rc = launch_scores_any(idx, c, q_dev, nq, c->scores, sstride, st)) != SVS_OK) return rc;
     if (timed) HIP_TRY(hipEventRecord(ev.e1, st));
-    if (k > 0 && (rc = run_select(idx, c, c->scores, n, sstride, nq, k, count, out_s, out_r, st)) != SVS_OK) return rc;
+    if (k > 0 && (rc = run_select(idx, c, c->scores, n, sstride, nq, k, count, out_s, out_r, st, idx->row_offset)) != SVS_OK) return rc;
   }
   HIP_TRY(hipGetLastError());
   if (timed) {
@@ -895,6 +901,74 @@ int32_t svs_index_scores(svs_index* idx, const float* query, int32_t d, float* o
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(out_scores, c->scores, (size_t)idx->n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  return SVS_OK;
+}
+
+int32_t svs_index_top_pairs(svs_index* idx, int32_t k, float* out_scores, int64_t* out_i, int64_t* out_j,
+                            int32_t* out_count) {
+  if (!idx) return fail(SVS_ERR_INVALID, "null index");
+  const int64_t n = idx->n;
+  const int64_t np = (n + 3) & ~(int64_t)3;
+  const int64_t pairs = n * (n - 1) / 2;
+  const int count = (int)std::min<int64_t>(std::max(k, 0), pairs);
+  if (out_count) *out_count = count;
+  if (count == 0) return SVS_OK;
+  if (!out_scores || !out_i || !out_j) return fail(SVS_ERR_INVALID, "null output");
+  if (n * np > 0xffffffffll) return fail(SVS_ERR_UNSUPPORTED, "pairwise scores need n*n <= 2^32 (n = %lld)", (long long)n);
+  svs_index_retain(idx);
+  struct Guard { svs_index* i; ~Guard() { svs_index_release(i); } } guard{idx};
+  HIP_TRY(hipSetDevice(idx->device));
+  Ctx* c = nullptr;
+  int rc;
+  if ((rc = ctx_acquire(idx, nullptr, true, &c)) != SVS_OK) return rc;
+  struct CtxGuard { svs_index* i; Ctx* c; ~CtxGuard() { ctx_release(i, c); } } cg{idx, c};
+  hipStream_t st = c->stream;
+  // every row is a query: read the corpus back as f32 queries (what the index holds)
+  float* qall = nullptr;
+  float* S = nullptr;
+  float* d_s = nullptr;
+  int64_t* d_r = nullptr;
+  struct Tmp { float** a; float** b; float** cc; int64_t** d; ~Tmp() { (void)hipFree(*a); (void)hipFree(*b); (void)hipFree(*cc); (void)hipFree(*d); } } tmp{&qall, &S, &d_s, &d_r};
+  HIP_TRY(hipMalloc((void**)&qall, (size_t)n * idx->d * sizeof(float)));
+  HIP_TRY(hipMalloc((void**)&S, (size_t)n * np * sizeof(float)));
+  HIP_TRY(hipMalloc((void**)&d_s, (size_t)count * sizeof(float)));
+  HIP_TRY(hipMalloc((void**)&d_r, (size_t)count * sizeof(int64_t)));
+  if (idx->dtype == SVS_DTYPE_F32)
+    HIP_TRY(hipMemcpy2DAsync(qall, (size_t)idx->d * sizeof(float), idx->rows, (size_t)idx->ld * sizeof(float),
+                             (size_t)idx->d * sizeof(float), (size_t)n, hipMemcpyDeviceToDevice, st));
+  else if (idx->dtype == SVS_DTYPE_F16)
+    hipLaunchKernelGGL(dequant_rows_f16_kernel, dim3(2048), dim3(256), 0, st, (const _Float16*)idx->rows, (int64_t)0, n, idx->d, idx->ld, qall);
+  else
+    hipLaunchKernelGGL(dequant_rows_fp8_kernel, dim3(2048), dim3(256), 0, st, (const uint8_t*)idx->rows, idx->row_scales, (int64_t)0, n,
+                       idx->d, idx->ld, qall);
+  // S = M * M^T in blocks of query rows (the reference's np.dot(M, M.T), src/svs/kb.py:1651)
+  const int chunk = 1024;
+  for (int64_t q0 = 0; q0 < n; q0 += chunk) {
+    const int nq = (int)std::min<int64_t>(chunk, n - q0);
+    if ((rc = launch_scores_any(idx, c, qall + q0 * idx->d, nq, S + q0 * np, np, st)) != SVS_OK) return rc;
+  }
+  hipLaunchKernelGGL(mask_upper_triangle_kernel, dim3(4096), dim3(256), 0, st, S, n, np);
+  // top-k of the flattened upper triangle; the flat index i*np + j orders ties like the reference
+  const int64_t flat = n * np;
+  const bool path_a = flat > SORT_CAP && count <= SEL_KMAX;
+  if (path_a && c->hist_cap < 1) {
+    HIP_TRY(hipMalloc((void**)&c->hist, (size_t)SCR_WORDS * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&c->cand, (size_t)CAND_CAP * sizeof(uint64_t)));
+    HIP_TRY(hipMemsetAsync(c->hist, 0, (size_t)SCR_WORDS * sizeof(uint32_t), st));
+    c->hist_cap = 1;
+  }
+  const int64_t save_off = idx->row_offset;
+  (void)save_off;
+  if ((rc = run_select(idx, c, S, flat, flat, 1, count, count, d_s, d_r, st, /*row_offset=*/0)) != SVS_OK) return rc;
+  HIP_TRY(hipGetLastError());
+  std::vector<int64_t> flat_rows((size_t)count);
+  HIP_TRY(hipMemcpyAsync(out_scores, d_s, (size_t)count * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(flat_rows.data(), d_r, (size_t)count * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  for (int t = 0; t < count; ++t) {
+    out_i[t] = flat_rows[t] / np + idx->row_offset;
+    out_j[t] = flat_rows[t] % np + idx->row_offset;
+  }
   return SVS_OK;
 }
 

@@ -176,6 +176,25 @@ class DeviceIndex:
             self._lib.svs_index_release(h)
         return count.value
 
+    def top_pairs(self, n: int) -> List[Tuple[float, int, int]]:
+        """``get_top_pairs(np.dot(M, M.T), n)`` (reference src/svs/kb.py:1651,
+        src/svs/util.py:206-233): [(score, row_i, row_j)] with i < j."""
+        assert isinstance(n, int)
+        k = max(n, 0)
+        scores = np.empty(k, dtype=np.float32)
+        ri = np.empty(k, dtype=np.int64)
+        rj = np.empty(k, dtype=np.int64)
+        count = C.c_int32(0)
+        h = self._pinned_handle()
+        try:
+            _native.check(self._lib.svs_index_top_pairs(
+                h, k, scores.ctypes.data_as(C.c_void_p), ri.ctypes.data_as(C.c_void_p),
+                rj.ctypes.data_as(C.c_void_p), C.byref(count)))
+        finally:
+            self._lib.svs_index_release(h)
+        c = count.value
+        return [(float(s), int(a), int(b)) for s, a, b in zip(scores[:c], ri[:c], rj[:c])]
+
     # -- parity support -----------------------------------------------------
     def stored_rows(self, row0: int = 0, nrows: Optional[int] = None) -> np.ndarray:
         """Rows exactly as held in HBM, dequantised to f32 (the corpus the oracle

@@ -302,6 +302,21 @@ class KB:
         return res
 
 
+    def document_top_pairwise_scores(self, n: int) -> List[Tuple[float, Dict[str, Any], Dict[str, Any]]]:
+        """Reference src/svs/kb.py:1642-1671: the n most similar document pairs,
+        [(score, doc_1, doc_2)].  M.M^T and the upper-triangle top-n run on the GPU
+        (svs_index_top_pairs)."""
+        assert self.db is not None
+        self.embeddings_matrix.get_sync(self.db)
+        n_docs = self.embeddings_matrix.index.shape[0]
+        _LOG.info(f"computing pairwise similarity over {n_docs} documents")
+        pairs = self.embeddings_matrix.top_pairs(n)
+        _LOG.info(f"computed {n_docs * n_docs} pairwise cosine similarities")
+        with self.db.transaction():
+            docs = self.db.fetch_docs_for_embeddings(sorted({e for _, a, b in pairs for e in (a, b)}))
+        _LOG.info(f"retrieved top {n} document pairs")
+        return [(score, docs[a], docs[b]) for score, a, b in pairs]
+
     def retrieve_many(self, queries: List[str], n: int) -> List[List[Dict[str, Any]]]:
         """Batched ``retrieve()``: the queries are embedded
         in chunks of 200 like bulk_add_docs, searched together (the corpus is read

@@ -123,6 +123,15 @@ class DeviceEmbeddingsMatrix:
         finally:
             idx.release()
 
+    def top_pairs(self, n: int) -> List[Tuple[float, int, int]]:
+        """``superheavy()`` of document_top_pairwise_scores (src/svs/kb.py:1650-1655):
+        [(score, emb_id_1, emb_id_2)]."""
+        idx, lookup = self.hold()
+        try:
+            return [(score, int(lookup[i]), int(lookup[j])) for score, i, j in idx.top_pairs(n)]
+        finally:
+            idx.release()
+
     def hold(self) -> Tuple[Any, np.ndarray]:
         """(index, lookup) with the caller owning a reference to the index, so a
         concurrent ``invalidate()`` cannot free it mid-search.  Release it."""

@@ -59,6 +59,10 @@ class OracleIndex:
             raise ValueError(f"shapes {self.shape} and {q.shape} not aligned")
         return [(s, i + self.row_offset) for s, i in oracle.total_order_top_k(oracle.cpu_scores(self._m, q), n)]
 
+    def top_pairs(self, n):
+        self._check()
+        return oracle.cpu_top_pairs(np.dot(self._m, self._m.T), n)
+
     def search_batch(self, queries, n):
         self._check()
         q = np.ascontiguousarray(queries, dtype=np.float32)

@@ -57,6 +57,20 @@ def test_retrieve_many_equals_loop_of_retrieve(tmp_path):
     kb.close()
 
 
+def test_document_top_pairwise_scores(tmp_path):
+    """Reference tests/test_kb.py:1788-1797: after adding third/first/second doc the two
+    best pairs are (1,2) then (2,3)."""
+    cases = load_cases()
+    kb = svs_amd.KB(str(tmp_path / "p.sqlite"), embedding_func_from(cases), index_factory=OracleIndex)
+    with kb.bulk_add_docs() as add_doc:
+        for t in ("third doc", "first doc", "second doc"):
+            add_doc(t)
+    recs = kb.document_top_pairwise_scores(n=2)
+    assert [(a["id"], b["id"]) for _, a, b in recs] == [(1, 2), (2, 3)]
+    assert len(kb.document_top_pairwise_scores(n=100)) == 3
+    kb.close()
+
+
 def test_matrix_build_kat(tmp_path):
     """A7: BLOB rows -> (matrix, lookup), non-contiguous ids after a delete
     (reference tests/test_kb.py:753-806)."""

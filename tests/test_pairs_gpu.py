@@ -1,0 +1,70 @@
+"""GPU: document_top_pairwise_scores path -- M.M^T + strict-upper-triangle top-k
+(reference src/svs/kb.py:1651, src/svs/util.py:206-233) against the numpy oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import svs_oracle as oracle
+from synth import corpus_and_query
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(got, exp, tol=1e-5):
+    assert len(got) == len(exp)
+    for (gs, gi, gj), (es, ei, ej) in zip(got, exp):
+        assert abs(gs - es) <= tol and gi < gj
+    # same pair list unless two pair scores are closer than the f32 noise
+    diff = [t for t, (g, e) in enumerate(zip(got, exp)) if (g[1], g[2]) != (e[1], e[2])]
+    for t in diff:
+        assert abs(got[t][0] - exp[t][0]) <= 2e-6, (t, got[t], exp[t])
+
+
+def test_golden_top_pairs(gpu):
+    from svs_amd import DeviceIndex
+    with open(os.path.join(os.path.dirname(__file__), "golden", "kb_cases.json")) as f:
+        g = json.load(f)["top_pairs"]
+    m = np.array(g["matrix"], dtype=np.float32)   # a pairwise matrix; factor it so that M.M^T reproduces it
+    # build vectors whose Gram matrix is exactly the golden matrix is not possible in general,
+    # so pin the SELECTION logic instead: a corpus of one-hot rows scaled to make M.M^T == matrix is
+    # replaced by running the selection on a Gram matrix we do know:
+    rng = np.random.default_rng(1)
+    v = rng.standard_normal((40, 8)).astype(np.float32)
+    idx = DeviceIndex(v)
+    gram = np.dot(v, v.T)
+    _check(idx.top_pairs(25), oracle.cpu_top_pairs(gram, 25))
+    idx.release()
+    assert [list(p) for p in oracle.cpu_top_pairs(m, g["k"])] == g["expected"]   # the oracle itself is pinned
+
+
+@pytest.mark.parametrize("n,d,k,dtype", [(300, 64, 50, "f32"), (1000, 1536, 100, "f32"), (2000, 256, 10000, "f32"),
+                                         (4875, 1536, 10000, "f32"), (1500, 1536, 300, "f16"), (257, 3, 40000, "f32")])
+def test_top_pairs_matches_oracle(gpu, n, d, k, dtype):
+    from svs_amd import DeviceIndex
+    m, _ = corpus_and_query("gaussian", 50 + n, n, d, 1)
+    idx = DeviceIndex(m, dtype=dtype)
+    md = idx.stored_rows()
+    got = idx.top_pairs(k)
+    exp = oracle.cpu_top_pairs(np.dot(md, md.T), k)
+    assert len(got) == min(k, n * (n - 1) // 2)
+    _check(got, exp)
+    idx.release()
+
+
+def test_top_pairs_ties_and_edges(gpu):
+    from svs_amd import DeviceIndex
+    # duplicate rows -> exact score ties; order must be (score desc, i desc, j desc)
+    base = np.eye(6, dtype=np.float32)
+    m = np.concatenate([base, base, base[:3]])          # 15 rows, many pairs with score exactly 1 or 0
+    idx = DeviceIndex(m)
+    got = idx.top_pairs(30)
+    exp = oracle.cpu_top_pairs(np.dot(m, m.T), 30)
+    assert [(i, j) for _, i, j in got] == [(i, j) for _, i, j in exp]
+    assert idx.top_pairs(0) == [] and idx.top_pairs(-2) == []
+    assert len(idx.top_pairs(10_000)) == 15 * 14 // 2
+    idx.release()
+    one = DeviceIndex(np.ones((1, 4), dtype=np.float32))
+    assert one.top_pairs(5) == []
+    one.release()
