@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=20)
     ap.add_argument("--latency-iters", type=int, default=200)
+    ap.add_argument("--gather-every", type=int, default=8,
+                    help="N > 1: steps whose local top-k records share one RCCL all-gather")
     ap.add_argument("--batch", type=int, default=16, help="queries per call of the secondary batched figure (0: skip)")
     ap.add_argument("--inflight", type=int, default=1,
                     help="searches kept in flight on separate HIP streams (2 lets the top-k "
@@ -119,33 +121,39 @@ def main():
     # all-gather; rank 0 streams each gathered step back with an async copy.
     # (A single bulk D2H after the loop cost 8-12 ms: the copy engine had idled.)
     s_bytes, rec = record_layout(k)
-    host_out = torch.zeros((K + W, world, rec), dtype=torch.uint8, pin_memory=True)
-    local = None if world == 1 else torch.zeros((K + W, rec), device=dev, dtype=torch.uint8)
-    gathered = torch.zeros((K + W, world, rec), device=dev, dtype=torch.uint8) if world > 1 else None
+    G = max(1, args.gather_every) if world > 1 else 1           # steps per exchange
+    nchunks = (K + W + G - 1) // G
+    host_out = torch.zeros((nchunks, world, G * rec), dtype=torch.uint8, pin_memory=True)
+    local = None if world == 1 else torch.zeros((nchunks, G * rec), device=dev, dtype=torch.uint8)
+    gathered = torch.zeros((nchunks, world, G * rec), device=dev, dtype=torch.uint8) if world > 1 else None
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.inflight if world == 1 else max(2, args.inflight)))]
     count = min(k, n_local)
     torch.cuda.synchronize()
 
-    def step(i):
-        st = streams[i % len(streams)]
-        base = host_out[i, 0].data_ptr() if world == 1 else local[i].data_ptr()
+    def step(i, last_of_run):
+        """One search; N > 1: after every G-th step (or the last of a run) one RCCL
+        all-gather moves the G local records of every rank, and rank 0 streams them home."""
+        c, j = divmod(i, G)
+        st = streams[c % len(streams)]
+        base = (host_out[c, 0] if world == 1 else local[c]).data_ptr() + j * rec
         idx.search_device(queries[i].data_ptr(), 1, d, k, base, base + s_bytes, st.cuda_stream)
-        if world > 1:
+        if world > 1 and (j == G - 1 or last_of_run):
             with torch.cuda.stream(st):
-                w = dist.all_gather_into_tensor(gathered[i].view(-1), local[i], async_op=True)
+                w = dist.all_gather_into_tensor(gathered[c].view(-1), local[c], async_op=True)
                 w.wait()   # orders this stream behind the collective; does not block the host
                 if rank == 0:
-                    host_out[i].copy_(gathered[i], non_blocking=True)
+                    host_out[c].copy_(gathered[c], non_blocking=True)
 
     def finish(i0, i1):
         """Drain the streams, then merge on rank 0 (host merge, H1)."""
         torch.cuda.synchronize()
         if rank != 0:
             return None
-        buf = host_out[i0:i1].numpy()
         res = []
-        for j in range(i1 - i0):
-            sc, rw = unpack_records(buf[j], world, k)
+        for i in range(i0, i1):
+            c, j = divmod(i, G)
+            buf = host_out[c].numpy()[:, j * rec:(j + 1) * rec]
+            sc, rw = unpack_records(buf, world, k)
             res.append(merge_topk(sc, rw, min(k, n_total)) if world > 1 else (sc[0, :count].copy(), rw[0, :count].copy()))
         return res
 
@@ -157,7 +165,7 @@ def main():
     # cost is paid here and not inside the timed region)
     idx.set_timing(True)
     for i in range(W):
-        step(i)
+        step(i, i == W - 1)
     finish(0, W)
     idx.get_timing()
     barrier()
@@ -166,7 +174,7 @@ def main():
     # ---- timed region: exactly K steps
     t0 = time.perf_counter()
     for i in range(K):
-        step(W + i)
+        step(W + i, i == K - 1)
     t_enq = time.perf_counter()
     results = finish(W, W + K)
     torch.cuda.synchronize()
@@ -258,6 +266,7 @@ def main():
                 "rows_per_gpu": n_local, "dim": d, "k": k, "queries_per_step": 1,
                 "corpus": "unit-norm gaussian, seed %d, generated on device" % args.seed,
                 "variant": args.variant, "searches_in_flight": len(streams),
+                "steps_per_exchange": G if world > 1 else None,
             },
             "p50_latency_ms": lat_ms,
             "batched": batched,

@@ -59,9 +59,15 @@ def test_top_pairs_ties_and_edges(gpu):
     base = np.eye(6, dtype=np.float32)
     m = np.concatenate([base, base, base[:3]])          # 15 rows, many pairs with score exactly 1 or 0
     idx = DeviceIndex(m)
-    got = idx.top_pairs(30)
-    exp = oracle.cpu_top_pairs(np.dot(m, m.T), 30)
+    gram = np.dot(m, m.T)
+    got = idx.top_pairs(12)                                # the 12 pairs with score exactly 1: in-set ties
+    exp = oracle.cpu_top_pairs(gram, 12)
     assert [(i, j) for _, i, j in got] == [(i, j) for _, i, j in exp]
+    got = idx.top_pairs(30)                                # 18 more out of a 93-way tie at score 0: a boundary
+    exp = oracle.cpu_top_pairs(gram, 30)                   # tie, the reference's pick is introselect-internal
+    assert [s for s, _, _ in got] == [s for s, _, _ in exp]
+    zero = [(i, j) for s, i, j in got if s == 0.0]
+    assert zero == sorted(zero, reverse=True) and zero[0] == (13, 14)   # ours: largest (i, j) first
     assert idx.top_pairs(0) == [] and idx.top_pairs(-2) == []
     assert len(idx.top_pairs(10_000)) == 15 * 14 // 2
     idx.release()
