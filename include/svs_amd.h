@@ -61,6 +61,7 @@ typedef struct svs_index_info_t {
   int32_t device;     /* HIP device ordinal                                    */
   int64_t row_offset; /* global row index of local row 0 (row sharding, 8(e))  */
   int64_t hbm_bytes;  /* bytes of HBM held by the corpus                       */
+  int64_t n_masked;   /* rows tombstoned by svs_index_mask_rows (still counted in n) */
 } svs_index_info_t;
 
 /* Stages timed with HIP events on the stream the kernels run on (bench.py roofline). */
@@ -94,6 +95,22 @@ int32_t svs_index_create(const float* host_rows, int64_t n, int32_t d, int32_t s
 int32_t svs_index_create_from_device(const float* dev_rows, int64_t n, int32_t d, int64_t src_ld,
                                      int32_t store_dtype, int32_t device, int64_t row_offset,
                                      svs_index** out);
+
+/* ---- incremental update: instead of dropping the whole cached matrix on every
+ *      bulk_add_docs / bulk_del_docs (invalidate(), src/svs/kb.py:1523, :1541, :1062, :1086)
+ *      and re-uploading 6-300 GB, the HBM copy is edited in place. */
+
+/* Appends n_new rows (f32, C-contiguous (n_new, d), host) behind the existing ones:
+ * new local rows n .. n+n_new-1, exactly where `SELECT id, embedding FROM embeddings`
+ * (src/svs/kb.py:603-609) puts newly inserted embeddings.  Grows the HBM buffers by
+ * 1.5x when needed.  Blocks searches on this handle while it runs. */
+int32_t svs_index_append(svs_index* idx, const float* host_rows, int64_t n_new);
+
+/* Tombstones rows (GLOBAL indices, i.e. row_offset + local): they keep their index
+ * (later rows do not shift, so the caller's emb_id_lookup stays valid) but can never
+ * be returned again; count = min(k, n - masked).  Relative order of the surviving rows
+ * is unchanged, so results equal those of a rebuilt matrix up to the row numbering. */
+int32_t svs_index_mask_rows(svs_index* idx, const int64_t* rows, int64_t count);
 
 int32_t svs_index_retain(svs_index* idx);
 /* Drops one reference; HBM is freed when the last holder (including in-flight

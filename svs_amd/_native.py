@@ -34,6 +34,7 @@ class IndexInfo(C.Structure):
         ("device", C.c_int32),
         ("row_offset", C.c_int64),
         ("hbm_bytes", C.c_int64),
+        ("n_masked", C.c_int64),
     ]
 
 
@@ -53,6 +54,8 @@ SIGNATURES = {
     "svs_device_count": (C.c_int32, []),
     "svs_index_create": (C.c_int32, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.POINTER(_P)]),
     "svs_index_create_from_device": (C.c_int32, [_P, C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.POINTER(_P)]),
+    "svs_index_append": (C.c_int32, [_P, _P, C.c_int64]),
+    "svs_index_mask_rows": (C.c_int32, [_P, _P, C.c_int64]),
     "svs_index_retain": (C.c_int32, [_P]),
     "svs_index_release": (C.c_int32, [_P]),
     "svs_index_info": (C.c_int32, [_P, C.POINTER(IndexInfo)]),

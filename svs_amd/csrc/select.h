@@ -387,6 +387,28 @@ __global__ void mask_upper_triangle_kernel(float* __restrict__ S, int64_t n, int
   }
 }
 
+// ---- tombstones (svs_index_mask_rows) ------------------------------------------
+// scores[q][row] = -inf for every masked (tombstoned) row
+__global__ void mask_dead_rows_kernel(float* __restrict__ scores, int64_t sstride, int nq,
+                                      const uint32_t* __restrict__ dead, int64_t n_dead) {
+  const int64_t total = n_dead * nq;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t q = t / n_dead;
+    scores[q * sstride + dead[t - q * n_dead]] = -__builtin_inff();
+  }
+}
+// pairwise matrix S[n][np]: whole row and column of a masked row -> -inf
+__global__ void mask_dead_pairs_kernel(float* __restrict__ S, int64_t n, int64_t np,
+                                       const uint32_t* __restrict__ dead, int64_t n_dead) {
+  const int64_t total = n_dead * n;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t di = t / n, j = t - di * n;
+    const int64_t r = dead[di];
+    S[r * np + j] = -__builtin_inff();
+    S[j * np + r] = -__builtin_inff();
+  }
+}
+
 // ---- path B: global bitonic sort of all keys --------------------------------
 // keys is [nq][npad], npad a power of two >= max(n, 2).
 __global__ void keys_build_kernel(const float* __restrict__ scores, int64_t n,

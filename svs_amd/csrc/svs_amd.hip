@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <shared_mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -82,9 +83,17 @@ struct svs_index {
   int64_t n = 0;
   int d = 0, ld = 0, dtype = SVS_DTYPE_F32;
   int64_t row_offset = 0;
+  int64_t cap = 0;               // rows the buffers can hold (append grows them)
   void* rows = nullptr;
   float* row_scales = nullptr;   // fp8 only: one f32 per row
   size_t bytes = 0;
+  // Corpus geometry lock: searches hold it shared while they enqueue (and, for the
+  // host API, until their results are back); append / mask_rows take it exclusive.
+  std::shared_mutex rw;
+  std::vector<uint8_t> dead_flag;      // host, one per row
+  std::vector<uint32_t> dead_list;     // host copy of the masked (tombstoned) local rows
+  uint32_t* dead_dev = nullptr;        // device copy
+  size_t dead_dev_cap = 0;
   int cu_count = 256;
 
   std::mutex mu;
@@ -133,6 +142,7 @@ void index_destroy(svs_index* idx) {
   }
   (void)hipFree(idx->rows);
   (void)hipFree(idx->row_scales);
+  (void)hipFree(idx->dead_dev);
   delete idx;
 }
 
@@ -556,7 +566,7 @@ int enqueue_search(svs_index* idx, Ctx* c, const float* q_dev, int nq, int k, in
   // Fused top-k epilogue (no score matrix): batched f16 GEMM only; a query whose
   // candidate list overflows comes back marked and is re-run by the caller.
   const bool fused = allow_fused && path_a && nq >= 64 && n >= 8 * FUSE_PREFIX_MIN && tiled_ok(idx) &&
-                     count <= 256 && idx->variant.load() != 6;
+                     count <= 256 && idx->dead_list.empty() && idx->variant.load() != 6;
   const int64_t n_mat = fused ? fuse_prefix_rows(n) : n;     // rows of the materialised score matrix
   const int64_t sstride = (n_mat + 3) & ~(int64_t)3;         // float4-aligned score vectors
   if ((rc = grow_dev(&c->scores, &c->scores_cap, (size_t)nq * (size_t)sstride)) != SVS_OK) return rc;
@@ -594,6 +604,9 @@ int enqueue_search(svs_index* idx, Ctx* c, const float* q_dev, int nq, int k, in
                        c->hist, c->cand, idx->row_offset, out_s, out_r);
   } else {
     if ((rc = launch_scores_any(idx, c, q_dev, nq, c->scores, sstride, st)) != SVS_OK) return rc;
+    if (!idx->dead_list.empty())   // tombstoned rows can never be returned
+      hipLaunchKernelGGL(mask_dead_rows_kernel, dim3(64), dim3(256), 0, st, c->scores, sstride, nq, idx->dead_dev,
+                         (int64_t)idx->dead_list.size());
     if (timed) HIP_TRY(hipEventRecord(ev.e1, st));
     if (k > 0 && (rc = run_select(idx, c, c->scores, n, sstride, nq, k, count, out_s, out_r, st, idx->row_offset)) != SVS_OK) return rc;
   }
@@ -616,6 +629,68 @@ int check_query_args(const svs_index* idx, const void* q, int nq, int d) {
   return SVS_OK;
 }
 
+// Host rows [0, nrows) (f32, C-contiguous, d floats each) -> HBM rows [row0, row0+nrows).
+// Pinned double-buffered staging: host memcpy of chunk i+1 overlaps the DMA of chunk i.
+// f32 corpus: the DMA writes the padded HBM layout directly (2D copy).
+// f16 / fp8 corpus: the DMA lands in a device staging buffer and a kernel converts it.
+hipError_t upload_host_rows(svs_index* idx, const float* host_rows, int64_t nrows, int64_t row0) {
+  const int d = idx->d;
+  const int64_t n = nrows;
+  const bool f16 = idx->dtype != SVS_DTYPE_F32;   // f16 and fp8: convert on the device
+  const size_t row_b = (size_t)d * sizeof(float);
+  const size_t esz = idx->dtype == SVS_DTYPE_F32 ? 4 : (idx->dtype == SVS_DTYPE_F16 ? 2 : 1);
+  const size_t chunk_rows = std::max<size_t>(1, std::min<size_t>((32u << 20) / row_b, (size_t)n));
+  void* pin[2] = {nullptr, nullptr};
+  float* dstage[2] = {nullptr, nullptr};
+  hipEvent_t done[2] = {nullptr, nullptr};
+  hipStream_t st = nullptr;
+  hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+  for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+    e = hipHostMalloc(&pin[i], chunk_rows * row_b, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
+    if (e == hipSuccess && f16) e = hipMalloc((void**)&dstage[i], chunk_rows * row_b);
+  }
+  if (e == hipSuccess && !f16 && idx->ld != d)
+    e = hipMemsetAsync((char*)idx->rows + (size_t)row0 * idx->ld * esz, 0, (size_t)n * idx->ld * esz, st);
+  int b = 0;
+  for (size_t r0 = 0; r0 < (size_t)n && e == hipSuccess; r0 += chunk_rows, b ^= 1) {
+    const size_t rows = std::min(chunk_rows, (size_t)n - r0);
+    const size_t dr = (size_t)row0 + r0;   // destination row
+    e = hipEventSynchronize(done[b]);
+    if (e != hipSuccess) break;
+    memcpy(pin[b], host_rows + r0 * (size_t)d, rows * row_b);
+    if (f16) {
+      e = hipMemcpyAsync(dstage[b], pin[b], rows * row_b, hipMemcpyHostToDevice, st);
+      if (e == hipSuccess) {
+        if (idx->dtype == SVS_DTYPE_F16)
+          hipLaunchKernelGGL(convert_rows_f16_kernel, dim3(2048), dim3(256), 0, st, (const float*)dstage[b],
+                             (int64_t)rows, d, (int64_t)d, (_Float16*)idx->rows + dr * (size_t)idx->ld, idx->ld);
+        else
+          hipLaunchKernelGGL(quantize_rows_fp8_kernel, dim3(2048), dim3(256), 0, st, (const float*)dstage[b],
+                             (int64_t)rows, d, (int64_t)d, (uint8_t*)idx->rows + dr * (size_t)idx->ld, idx->ld,
+                             idx->row_scales + dr, (float*)nullptr);
+        e = hipGetLastError();
+      }
+    } else if (idx->ld == d) {
+      e = hipMemcpyAsync((float*)idx->rows + dr * (size_t)d, pin[b], rows * row_b, hipMemcpyHostToDevice, st);
+    } else {
+      e = hipMemcpy2DAsync((float*)idx->rows + dr * (size_t)idx->ld, (size_t)idx->ld * sizeof(float), pin[b], row_b,
+                           row_b, rows, hipMemcpyHostToDevice, st);
+    }
+    if (e == hipSuccess) e = hipEventRecord(done[b], st);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  for (int i = 0; i < 2; ++i) {
+    if (done[i]) (void)hipEventDestroy(done[i]);
+    if (pin[i]) (void)hipHostFree(pin[i]);
+    if (dstage[i]) (void)hipFree(dstage[i]);
+  }
+  if (st) (void)hipStreamDestroy(st);
+  return e;
+}
+
+size_t elem_bytes(const svs_index* idx) { return idx->dtype == SVS_DTYPE_F32 ? 4 : (idx->dtype == SVS_DTYPE_F16 ? 2 : 1); }
+
 int create_common(int64_t n, int32_t d, int32_t store_dtype, int32_t device, int64_t row_offset,
                   svs_index** out, svs_index** made) {
   if (!out) return fail(SVS_ERR_INVALID, "null out");
@@ -632,6 +707,7 @@ int create_common(int64_t n, int32_t d, int32_t store_dtype, int32_t device, int
   if (!idx) return fail(SVS_ERR_NOMEM, "host allocation failed");
   idx->device = device;
   idx->n = n;
+  idx->cap = n;
   idx->d = d;
   idx->dtype = store_dtype;
   // 16-byte aligned rows: 4 floats, 8 halves or 16 fp8 bytes
@@ -656,6 +732,7 @@ int create_common(int64_t n, int32_t d, int32_t store_dtype, int32_t device, int
       idx->bytes += (size_t)n * sizeof(float);
     }
   }
+  idx->dead_flag.assign((size_t)n, 0);
   *made = idx;
   return SVS_OK;
 }
@@ -683,56 +760,7 @@ int32_t svs_index_create(const float* host_rows, int64_t n, int32_t d, int32_t s
       index_destroy(idx);
       return fail(SVS_ERR_INVALID, "null host_rows");
     }
-    // pinned double-buffered staging: host memcpy of chunk i+1 overlaps the DMA of chunk i.
-    // f32 corpus: the DMA writes the padded HBM layout directly (2D copy).
-    // f16 corpus: the DMA lands in a device staging buffer and a kernel rounds it to half.
-    const bool f16 = idx->dtype != SVS_DTYPE_F32;   // f16 and fp8: convert on the device
-    const size_t row_b = (size_t)d * sizeof(float);
-    const size_t chunk_rows = std::max<size_t>(1, (32u << 20) / row_b);
-    void* pin[2] = {nullptr, nullptr};
-    float* dstage[2] = {nullptr, nullptr};
-    hipEvent_t done[2] = {nullptr, nullptr};
-    hipStream_t st = nullptr;
-    hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
-    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
-      e = hipHostMalloc(&pin[i], chunk_rows * row_b, hipHostMallocDefault);
-      if (e == hipSuccess) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
-      if (e == hipSuccess && f16) e = hipMalloc((void**)&dstage[i], chunk_rows * row_b);
-    }
-    if (e == hipSuccess && !f16 && idx->ld != d) e = hipMemsetAsync(idx->rows, 0, idx->bytes, st);
-    int b = 0;
-    for (size_t r0 = 0; r0 < (size_t)n && e == hipSuccess; r0 += chunk_rows, b ^= 1) {
-      const size_t rows = std::min(chunk_rows, (size_t)n - r0);
-      e = hipEventSynchronize(done[b]);
-      if (e != hipSuccess) break;
-      memcpy(pin[b], host_rows + r0 * (size_t)d, rows * row_b);
-      if (f16) {
-        e = hipMemcpyAsync(dstage[b], pin[b], rows * row_b, hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) {
-          if (idx->dtype == SVS_DTYPE_F16)
-            hipLaunchKernelGGL(convert_rows_f16_kernel, dim3(2048), dim3(256), 0, st, (const float*)dstage[b],
-                               (int64_t)rows, d, (int64_t)d, (_Float16*)idx->rows + r0 * (size_t)idx->ld, idx->ld);
-          else
-            hipLaunchKernelGGL(quantize_rows_fp8_kernel, dim3(2048), dim3(256), 0, st, (const float*)dstage[b],
-                               (int64_t)rows, d, (int64_t)d, (uint8_t*)idx->rows + r0 * (size_t)idx->ld, idx->ld,
-                               idx->row_scales + r0, (float*)nullptr);
-          e = hipGetLastError();
-        }
-      } else if (idx->ld == d) {
-        e = hipMemcpyAsync((float*)idx->rows + r0 * (size_t)d, pin[b], rows * row_b, hipMemcpyHostToDevice, st);
-      } else {
-        e = hipMemcpy2DAsync((float*)idx->rows + r0 * (size_t)idx->ld, (size_t)idx->ld * sizeof(float), pin[b], row_b,
-                             row_b, rows, hipMemcpyHostToDevice, st);
-      }
-      if (e == hipSuccess) e = hipEventRecord(done[b], st);
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    for (int i = 0; i < 2; ++i) {
-      if (done[i]) (void)hipEventDestroy(done[i]);
-      if (pin[i]) (void)hipHostFree(pin[i]);
-      if (dstage[i]) (void)hipFree(dstage[i]);
-    }
-    if (st) (void)hipStreamDestroy(st);
+    hipError_t e = upload_host_rows(idx, host_rows, n, 0);
     if (e != hipSuccess) {
       index_destroy(idx);
       return fail(SVS_ERR_DEVICE, "corpus upload: %s", hipGetErrorString(e));
@@ -778,6 +806,79 @@ int32_t svs_index_create_from_device(const float* dev_rows, int64_t n, int32_t d
   return SVS_OK;
 }
 
+int32_t svs_index_append(svs_index* idx, const float* host_rows, int64_t n_new) {
+  if (!idx) return fail(SVS_ERR_INVALID, "null index");
+  if (n_new < 0) return fail(SVS_ERR_INVALID, "negative row count");
+  if (n_new == 0) return SVS_OK;
+  if (!host_rows) return fail(SVS_ERR_INVALID, "null host_rows");
+  if (idx->d == 0) return fail(SVS_ERR_SHAPE, "cannot append to a zero-dimensional index");
+  std::unique_lock<std::shared_mutex> geo(idx->rw);   // no search is enqueuing while the geometry changes
+  HIP_TRY(hipSetDevice(idx->device));
+  const int64_t n_old = idx->n, n_tot = n_old + n_new;
+  if (n_tot > 0xffffffffll) return fail(SVS_ERR_INVALID, "at most 2^32 rows per handle; shard the corpus");
+  const size_t esz = elem_bytes(idx), row_b = (size_t)idx->ld * esz;
+  if (n_tot > idx->cap) {
+    // grow by 1.5x; work already enqueued by the device API may still read the old buffers
+    const int64_t new_cap = std::max<int64_t>(n_tot, idx->cap + idx->cap / 2 + 1024);
+    void* nrows = nullptr;
+    float* nscales = nullptr;
+    HIP_TRY(hipMalloc(&nrows, (size_t)new_cap * row_b));
+    if (idx->dtype == SVS_DTYPE_FP8) {
+      hipError_t e = hipMalloc((void**)&nscales, (size_t)new_cap * sizeof(float));
+      if (e != hipSuccess) {
+        (void)hipFree(nrows);
+        return fail(SVS_ERR_NOMEM, "hipMalloc(row scales): %s", hipGetErrorString(e));
+      }
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    if (n_old) HIP_TRY(hipMemcpy(nrows, idx->rows, (size_t)n_old * row_b, hipMemcpyDeviceToDevice));
+    if (n_old && nscales) HIP_TRY(hipMemcpy(nscales, idx->row_scales, (size_t)n_old * sizeof(float), hipMemcpyDeviceToDevice));
+    (void)hipFree(idx->rows);
+    (void)hipFree(idx->row_scales);
+    idx->rows = nrows;
+    idx->row_scales = nscales;
+    idx->cap = new_cap;
+  }
+  hipError_t e = upload_host_rows(idx, host_rows, n_new, n_old);
+  if (e != hipSuccess) return fail(SVS_ERR_DEVICE, "append upload: %s", hipGetErrorString(e));
+  idx->n = n_tot;
+  idx->dead_flag.resize((size_t)n_tot, 0);
+  idx->bytes = (size_t)idx->cap * row_b + (idx->dtype == SVS_DTYPE_FP8 ? (size_t)idx->cap * sizeof(float) : 0);
+  return SVS_OK;
+}
+
+int32_t svs_index_mask_rows(svs_index* idx, const int64_t* rows, int64_t count) {
+  if (!idx) return fail(SVS_ERR_INVALID, "null index");
+  if (count < 0 || (count > 0 && !rows)) return fail(SVS_ERR_INVALID, "bad row list");
+  std::unique_lock<std::shared_mutex> geo(idx->rw);
+  for (int64_t t = 0; t < count; ++t) {
+    const int64_t r = rows[t] - idx->row_offset;
+    if (r < 0 || r >= idx->n) return fail(SVS_ERR_INVALID, "row %lld out of range", (long long)rows[t]);
+  }
+  bool changed = false;
+  for (int64_t t = 0; t < count; ++t) {
+    const int64_t r = rows[t] - idx->row_offset;
+    if (!idx->dead_flag[(size_t)r]) {
+      idx->dead_flag[(size_t)r] = 1;
+      idx->dead_list.push_back((uint32_t)r);
+      changed = true;
+    }
+  }
+  if (!changed) return SVS_OK;
+  HIP_TRY(hipSetDevice(idx->device));
+  if (idx->dead_list.size() > idx->dead_dev_cap) {
+    HIP_TRY(hipDeviceSynchronize());   // enqueued searches may still read the old list
+    (void)hipFree(idx->dead_dev);
+    idx->dead_dev = nullptr;
+    idx->dead_dev_cap = 0;
+    const size_t cap = idx->dead_list.size() * 2 + 64;
+    HIP_TRY(hipMalloc((void**)&idx->dead_dev, cap * sizeof(uint32_t)));
+    idx->dead_dev_cap = cap;
+  }
+  HIP_TRY(hipMemcpy(idx->dead_dev, idx->dead_list.data(), idx->dead_list.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  return SVS_OK;
+}
+
 int32_t svs_index_retain(svs_index* idx) {
   if (!idx) return fail(SVS_ERR_INVALID, "null index");
   idx->refs.fetch_add(1);
@@ -799,14 +900,17 @@ int32_t svs_index_info(const svs_index* idx, svs_index_info_t* out) {
   out->device = idx->device;
   out->row_offset = idx->row_offset;
   out->hbm_bytes = (int64_t)idx->bytes;
+  out->n_masked = (int64_t)idx->dead_list.size();
   return SVS_OK;
 }
 
 int32_t svs_index_search(svs_index* idx, const float* queries, int32_t nq, int32_t d, int32_t k,
                          float* out_scores, int64_t* out_rows, int32_t* out_count) {
+  if (!idx) return fail(SVS_ERR_INVALID, "null index");
+  std::shared_lock<std::shared_mutex> geo(idx->rw);
   int rc = check_query_args(idx, queries, nq, d);
   if (rc != SVS_OK) return rc;
-  const int count = (int)std::min<int64_t>(std::max(k, 0), idx->n);
+  const int count = (int)std::min<int64_t>(std::max(k, 0), idx->n - (int64_t)idx->dead_list.size());
   if (out_count) *out_count = count;
   if (nq == 0 || count == 0) return SVS_OK;
   if (!out_scores || !out_rows) return fail(SVS_ERR_INVALID, "null output");
@@ -862,9 +966,11 @@ int32_t svs_index_search(svs_index* idx, const float* queries, int32_t nq, int32
 int32_t svs_index_search_device(svs_index* idx, const float* dev_queries, int32_t nq, int32_t d,
                                 int32_t k, float* dev_out_scores, int64_t* dev_out_rows,
                                 int32_t* out_count, void* hip_stream) {
+  if (!idx) return fail(SVS_ERR_INVALID, "null index");
+  std::shared_lock<std::shared_mutex> geo(idx->rw);
   int rc = check_query_args(idx, dev_queries, nq, d);
   if (rc != SVS_OK) return rc;
-  const int count = (int)std::min<int64_t>(std::max(k, 0), idx->n);
+  const int count = (int)std::min<int64_t>(std::max(k, 0), idx->n - (int64_t)idx->dead_list.size());
   if (out_count) *out_count = count;
   if (nq == 0 || k <= 0) return SVS_OK;
   if (!dev_out_scores || !dev_out_rows) return fail(SVS_ERR_INVALID, "null output");
@@ -885,6 +991,8 @@ int32_t svs_index_search_device(svs_index* idx, const float* dev_queries, int32_
 }
 
 int32_t svs_index_scores(svs_index* idx, const float* query, int32_t d, float* out_scores) {
+  if (!idx) return fail(SVS_ERR_INVALID, "null index");
+  std::shared_lock<std::shared_mutex> geo(idx->rw);
   int rc = check_query_args(idx, query, 1, d);
   if (rc != SVS_OK) return rc;
   if (!out_scores) return fail(SVS_ERR_INVALID, "null output");
@@ -907,9 +1015,11 @@ int32_t svs_index_scores(svs_index* idx, const float* query, int32_t d, float* o
 int32_t svs_index_top_pairs(svs_index* idx, int32_t k, float* out_scores, int64_t* out_i, int64_t* out_j,
                             int32_t* out_count) {
   if (!idx) return fail(SVS_ERR_INVALID, "null index");
+  std::shared_lock<std::shared_mutex> geo(idx->rw);
   const int64_t n = idx->n;
   const int64_t np = (n + 3) & ~(int64_t)3;
-  const int64_t pairs = n * (n - 1) / 2;
+  const int64_t n_live = n - (int64_t)idx->dead_list.size();
+  const int64_t pairs = n_live * (n_live - 1) / 2;
   const int count = (int)std::min<int64_t>(std::max(k, 0), pairs);
   if (out_count) *out_count = count;
   if (count == 0) return SVS_OK;
@@ -948,6 +1058,8 @@ int32_t svs_index_top_pairs(svs_index* idx, int32_t k, float* out_scores, int64_
     if ((rc = launch_scores_any(idx, c, qall + q0 * idx->d, nq, S + q0 * np, np, st)) != SVS_OK) return rc;
   }
   hipLaunchKernelGGL(mask_upper_triangle_kernel, dim3(4096), dim3(256), 0, st, S, n, np);
+  if (!idx->dead_list.empty())
+    hipLaunchKernelGGL(mask_dead_pairs_kernel, dim3(1024), dim3(256), 0, st, S, n, np, idx->dead_dev, (int64_t)idx->dead_list.size());
   // top-k of the flattened upper triangle; the flat index i*np + j orders ties like the reference
   const int64_t flat = n * np;
   const bool path_a = flat > SORT_CAP && count <= SEL_KMAX;

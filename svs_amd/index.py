@@ -50,11 +50,15 @@ class DeviceIndex:
                 m.ctypes.data_as(C.c_void_p), m.shape[0], m.shape[1], _DTYPES[dtype],
                 int(device), int(row_offset), C.byref(out)))
             self._h = out.value
+        self._refresh()
+
+    def _refresh(self) -> None:
         info = _native.IndexInfo()
-        _native.check(self._lib.svs_index_info(self._h, C.byref(info)))
+        _native.check(self._lib.svs_index_info(self._handle(), C.byref(info)))
         self.n, self.d, self.ld = int(info.n), int(info.d), int(info.ld)
         self.device, self.row_offset = int(info.device), int(info.row_offset)
         self.hbm_bytes = int(info.hbm_bytes)
+        self.n_masked = int(info.n_masked)
         self.dtype = {v: k for k, v in _DTYPES.items()}[int(info.dtype)]
 
     @classmethod
@@ -107,6 +111,23 @@ class DeviceIndex:
             h = self._handle()
             self._lib.svs_index_retain(h)
             return h
+
+    # -- incremental update ---------------------------------
+    def append(self, matrix: np.ndarray) -> None:
+        """New rows behind the existing ones (what a rebuilt matrix would hold after
+        ``bulk_add_docs``), without re-uploading the corpus."""
+        m = np.ascontiguousarray(matrix, dtype=np.float32)
+        if m.ndim != 2 or (m.shape[0] and m.shape[1] != self.d):
+            raise ValueError(f"cannot append shape {m.shape} to an index of dimension {self.d}")
+        _native.check(self._lib.svs_index_append(self._handle(), m.ctypes.data_as(C.c_void_p), m.shape[0]))
+        self._refresh()
+
+    def mask_rows(self, rows) -> None:
+        """Tombstone rows (global indices): they are never returned again; the other
+        rows keep their indices."""
+        r = np.ascontiguousarray(rows, dtype=np.int64)
+        _native.check(self._lib.svs_index_mask_rows(self._handle(), r.ctypes.data_as(C.c_void_p), r.shape[0]))
+        self._refresh()
 
     def share(self) -> "DeviceIndex":
         """A second owner of the same HBM copy (its own reference): what an

@@ -131,19 +131,22 @@ class _Store:
             (parent_id, level, text, json.dumps(meta) if meta is not None else None))
         return int(cur.lastrowid)
 
-    def set_doc_embedding(self, doc_id: int, blob: bytes) -> None:
+    def set_doc_embedding(self, doc_id: int, blob: bytes) -> int:
         cur = self.conn.execute("INSERT INTO embeddings (embedding) VALUES (?)", (blob,))
         res = self.conn.execute("UPDATE docs SET embedding = ? WHERE id = ?", (cur.lastrowid, doc_id))
         if res.rowcount != 1:
             raise KeyError(doc_id)
+        return int(cur.lastrowid)
 
-    def del_doc(self, doc_id: int) -> None:
+    def del_doc(self, doc_id: int) -> Optional[int]:
+        """Returns the id of the embedding that went with the document (if any)."""
         row = self.conn.execute("SELECT embedding FROM docs WHERE id = ?", (doc_id,)).fetchone()
         if row is None:
             raise KeyError(doc_id)
         self.conn.execute("DELETE FROM docs WHERE id = ?", (doc_id,))
         if row[0] is not None:
             self.conn.execute("DELETE FROM embeddings WHERE id = ?", (row[0],))
+        return row[0]
 
     def count_docs(self) -> int:
         return int(self.conn.execute("SELECT COUNT(*) FROM docs").fetchone()[0])
@@ -216,7 +219,7 @@ class KB:
         self.embedding_func = embedding_func
         self.db: Optional[_Store] = _Store(local_path)
         self.embeddings_matrix = DeviceEmbeddingsMatrix(device=device, builder=_build_from_store,
-                                                        index_factory=index_factory)
+                                                        index_factory=index_factory, keep_host_matrix=False)
         self._loop = asyncio.new_event_loop()
 
     # -- embedding helpers (A8) -------------------------------------------------
@@ -252,45 +255,63 @@ class KB:
         transaction, embeddings are fetched in chunks of 200 at exit, then the
         cached matrix is invalidated."""
         assert self.db is not None
-        with self.db.transaction():
-            live = True
-            pending: List[Tuple[int, str]] = []
+        new_ids: List[int] = []
+        new_vecs: List[List[float]] = []
+        try:
+            with self.db.transaction():
+                live = True
+                pending: List[Tuple[int, str]] = []
 
-            def add_doc(text: str, parent_id: Optional[int] = None, meta: Optional[Dict[str, Any]] = None,
-                        no_embedding: bool = False) -> int:
-                assert live, "You may not call this function outside of the context manager!"
-                doc_id = self.db.add_doc(text, parent_id, meta)
-                if not no_embedding:
-                    pending.append((doc_id, text))
-                return doc_id
+                def add_doc(text: str, parent_id: Optional[int] = None, meta: Optional[Dict[str, Any]] = None,
+                            no_embedding: bool = False) -> int:
+                    assert live, "You may not call this function outside of the context manager!"
+                    doc_id = self.db.add_doc(text, parent_id, meta)
+                    if not no_embedding:
+                        pending.append((doc_id, text))
+                    return doc_id
 
-            try:
-                yield add_doc
-            finally:
-                live = False
-            for c0 in range(0, len(pending), BULK_EMBEDDING_CHUNK_SIZE):
-                chunk = pending[c0:c0 + BULK_EMBEDDING_CHUNK_SIZE]
-                vectors = self._embed([t for _, t in chunk])
-                for (doc_id, _), vec in zip(chunk, vectors):
-                    self.db.set_doc_embedding(doc_id, embedding_to_bytes(vec))
+                try:
+                    yield add_doc
+                finally:
+                    live = False
+                for c0 in range(0, len(pending), BULK_EMBEDDING_CHUNK_SIZE):
+                    chunk = pending[c0:c0 + BULK_EMBEDDING_CHUNK_SIZE]
+                    vectors = self._embed([t for _, t in chunk])
+                    for (doc_id, _), vec in zip(chunk, vectors):
+                        new_ids.append(self.db.set_doc_embedding(doc_id, embedding_to_bytes(vec)))
+                        new_vecs.append(vec)
+        except BaseException:
             self.embeddings_matrix.invalidate()
+            raise
+        # committed: the reference drops the whole cached matrix here (kb.py:1523); the
+        # HBM copy is instead extended in place (falls back to invalidate when not loaded)
+        if new_ids:
+            self.embeddings_matrix.append(np.array(new_vecs, dtype=np.float32), new_ids)
 
     @contextmanager
     def bulk_del_docs(self) -> Iterator[Callable[[int], None]]:
         """Reference src/svs/kb.py:1526-1542."""
         assert self.db is not None
-        with self.db.transaction():
-            live = True
+        gone: List[int] = []
+        try:
+            with self.db.transaction():
+                live = True
 
-            def del_doc(doc_id: int) -> None:
-                assert live, "You may not call this function outside of the context manager!"
-                self.db.del_doc(doc_id)
+                def del_doc(doc_id: int) -> None:
+                    assert live, "You may not call this function outside of the context manager!"
+                    emb_id = self.db.del_doc(doc_id)
+                    if emb_id is not None:
+                        gone.append(emb_id)
 
-            try:
-                yield del_doc
-            finally:
-                live = False
+                try:
+                    yield del_doc
+                finally:
+                    live = False
+        except BaseException:
             self.embeddings_matrix.invalidate()
+            raise
+        if gone:   # reference: invalidate() (kb.py:1541); here the rows are tombstoned in HBM
+            self.embeddings_matrix.remove(gone)
 
     def retrieve(self, query: str, n: int) -> List[Dict[str, Any]]:
         """Reference src/svs/kb.py:1608-1640.  Same four log lines, same result
@@ -360,7 +381,7 @@ class AsyncKB:
         self.db: Optional[_Store] = None
         self._lock: Optional[asyncio.Lock] = None
         self.embeddings_matrix = DeviceEmbeddingsMatrix(device=device, builder=_build_from_store,
-                                                        index_factory=index_factory)
+                                                        index_factory=index_factory, keep_host_matrix=False)
 
     def _get_lock(self) -> asyncio.Lock:
         if self._lock is None:
@@ -415,38 +436,50 @@ class AsyncKB:
                     yield add_doc
                 finally:
                     live = False
+                new_ids: List[int] = []
+                new_vecs: List[List[float]] = []
                 for c0 in range(0, len(pending), BULK_EMBEDDING_CHUNK_SIZE):
                     chunk = pending[c0:c0 + BULK_EMBEDDING_CHUNK_SIZE]
                     vectors = await self._embed([t for _, t in chunk])
                     for (doc_id, _), vec in zip(chunk, vectors):
-                        db.set_doc_embedding(doc_id, embedding_to_bytes(vec))
+                        new_ids.append(db.set_doc_embedding(doc_id, embedding_to_bytes(vec)))
+                        new_vecs.append(vec)
             except BaseException:
                 db.conn.execute("ROLLBACK")
+                self.embeddings_matrix.invalidate()
                 raise
             else:
                 db.conn.execute("COMMIT")
-            self.embeddings_matrix.invalidate()
+            if new_ids:   # extend the HBM copy in place (reference: invalidate(), kb.py:1062)
+                loop = asyncio.get_running_loop()
+                await loop.run_in_executor(None, lambda: self.embeddings_matrix.append(
+                    np.array(new_vecs, dtype=np.float32), new_ids))
 
     @asynccontextmanager
     async def bulk_del_docs(self):
         async with self._get_lock():
             db = await self._ensure_db()
             live = True
+            gone: List[int] = []
             db.conn.execute("BEGIN")
             try:
                 async def del_doc(doc_id: int) -> None:
                     assert live, "You may not call this function outside of the context manager!"
-                    db.del_doc(doc_id)
+                    emb_id = db.del_doc(doc_id)
+                    if emb_id is not None:
+                        gone.append(emb_id)
                 try:
                     yield del_doc
                 finally:
                     live = False
             except BaseException:
                 db.conn.execute("ROLLBACK")
+                self.embeddings_matrix.invalidate()
                 raise
             else:
                 db.conn.execute("COMMIT")
-            self.embeddings_matrix.invalidate()
+            if gone:      # tombstone in HBM (reference: invalidate(), kb.py:1086)
+                self.embeddings_matrix.remove(gone)
 
     async def retrieve(self, query: str, n: int) -> List[Dict[str, Any]]:
         """Reference src/svs/kb.py:1171-1206."""
@@ -462,7 +495,8 @@ class AsyncKB:
             _LOG.info("got embedding for query!")
 
             def superheavy() -> List[Tuple[float, int]]:
-                return [(score, int(lookup[row])) for score, row in idx.search(query_vec, n)]
+                res = idx.search(query_vec, n)
+                return [(score, int(lookup.arr[row])) for score, row in res]
 
             emb_ids = await loop.run_in_executor(None, superheavy)
             _LOG.info(f"computed {idx.shape[0]} cosine similarities")

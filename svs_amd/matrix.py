@@ -40,9 +40,22 @@ def _default_builder(db) -> Tuple[np.ndarray, np.ndarray]:
         return q.build_embeddings_matrix()
 
 
+class _Lookup:
+    """Row -> embedding-id table of one loaded matrix.  ``arr`` only ever grows
+    (append) and masked rows are never returned, so a search that started before an
+    append can map its rows through the CURRENT array; a search that outlives an
+    ``invalidate()`` keeps this object (and so the right table) alive."""
+
+    def __init__(self, arr: np.ndarray):
+        self.arr = arr
+
+
 class DeviceEmbeddingsMatrix:
     """Lazy cache of (DeviceIndex, emb_id_lookup); drop-in for
     ``svs.kb._EmbeddingsMatrix``."""
+
+    # rebuild from storage instead of tombstoning once this share of the rows is dead
+    COMPACT_AT = 0.25
 
     def __init__(self, device: int = 0, builder: MatrixBuilder = _default_builder,
                  index_factory: Callable[..., Any] = DeviceIndex, keep_host_matrix: bool = True,
@@ -55,7 +68,13 @@ class DeviceEmbeddingsMatrix:
         self._mu = threading.Lock()
         self.index: Optional[Any] = None
         self.embeddings_matrix: Optional[np.ndarray] = None   # host copy (pairwise path), optional
-        self.emb_id_lookup: Optional[np.ndarray] = None
+        self._lookup: Optional[_Lookup] = None
+        self._n_dead = 0
+
+    @property
+    def emb_id_lookup(self) -> Optional[np.ndarray]:
+        lk = self._lookup
+        return lk.arr if lk is not None else None
 
     # -- reference surface ------------------------------------------------
     def invalidate(self) -> None:
@@ -65,7 +84,8 @@ class DeviceEmbeddingsMatrix:
         with self._mu:
             idx, self.index = self.index, None
             self.embeddings_matrix = None
-            self.emb_id_lookup = None
+            self._lookup = None
+            self._n_dead = 0
         if idx is not None:
             idx.release()
 
@@ -73,9 +93,62 @@ class DeviceEmbeddingsMatrix:
         idx = self._index_factory(matrix, device=self.device)
         with self._mu:
             self.index = idx
-            self.emb_id_lookup = lookup
+            self._lookup = _Lookup(lookup)
+            self._n_dead = 0
             self.embeddings_matrix = matrix if self._keep_host else None
         return idx
+
+    # -- incremental update ---------------------------------
+    def append(self, new_rows: np.ndarray, new_ids) -> bool:
+        """Rows a ``bulk_add_docs`` just committed, in embedding-id order (the order
+        ``SELECT id, embedding FROM embeddings`` would return them, src/svs/kb.py:603).
+        Edits the HBM copy in place; False if nothing is loaded (the next ``get``
+        builds from storage anyway)."""
+        new_rows = np.ascontiguousarray(new_rows, dtype=np.float32)
+        ids = np.asarray(new_ids, dtype=np.int64)
+        with self._mu:
+            idx, lk = self.index, self._lookup
+            if idx is None or lk is None:
+                return False
+            if len(ids) == 0:
+                return True
+            if new_rows.ndim != 2 or new_rows.shape[0] != len(ids) or (len(lk.arr) and ids[0] <= lk.arr[-1]) \
+                    or np.any(np.diff(ids) <= 0) or new_rows.shape[1] != idx.shape[1]:
+                idx = None   # not a pure append (or dimension change): rebuild
+            else:
+                idx.append(new_rows)
+                lk.arr = np.concatenate([lk.arr, ids])
+                if self.embeddings_matrix is not None:
+                    self.embeddings_matrix = np.vstack([self.embeddings_matrix, new_rows])
+        if idx is None:
+            self.invalidate()
+            return False
+        return True
+
+    def remove(self, emb_ids) -> bool:
+        """Embeddings a ``bulk_del_docs`` just committed: their rows are tombstoned in
+        HBM (never returned again, other rows keep their indices)."""
+        ids = np.asarray(list(emb_ids), dtype=np.int64)
+        rebuild = False
+        with self._mu:
+            idx, lk = self.index, self._lookup
+            if idx is None or lk is None:
+                return False
+            if len(ids) == 0:
+                return True
+            pos = np.searchsorted(lk.arr, ids)
+            if np.any(pos >= len(lk.arr)) or np.any(lk.arr[np.minimum(pos, len(lk.arr) - 1)] != ids):
+                rebuild = True
+            else:
+                self._n_dead += len(ids)
+                if self._n_dead > self.COMPACT_AT * len(lk.arr) or self.embeddings_matrix is not None:
+                    rebuild = True      # compaction (or a host copy would go stale): rebuild from storage
+                else:
+                    idx.mask_rows(pos + getattr(idx, "row_offset", 0))
+        if rebuild:
+            self.invalidate()
+            return False
+        return True
 
     def _result(self):
         m = DeviceMatrixView(self.index, self.embeddings_matrix) if self._view else self.embeddings_matrix
@@ -83,7 +156,7 @@ class DeviceEmbeddingsMatrix:
 
     def get_sync(self, db) -> Tuple[Any, np.ndarray]:
         """src/svs/kb.py:866-877."""
-        if self.index is not None and self.emb_id_lookup is not None:
+        if self.index is not None and self._lookup is not None:
             _LOG.info("using cached vectors")
             return self._result()
         _LOG.info("re-building cached vectors...")
@@ -94,7 +167,7 @@ class DeviceEmbeddingsMatrix:
 
     async def get(self, db) -> Tuple[Any, np.ndarray]:
         """src/svs/kb.py:879-893 (the build runs on an executor thread)."""
-        if self.index is not None and self.emb_id_lookup is not None:
+        if self.index is not None and self._lookup is not None:
             _LOG.info("using cached vectors")
             return self._result()
         _LOG.info("re-building cached vectors...")
@@ -109,7 +182,8 @@ class DeviceEmbeddingsMatrix:
         """``superheavy()`` (src/svs/kb.py:1622-1627): [(score, emb_id)]."""
         idx, lookup = self.hold()
         try:
-            return [(score, int(lookup[row])) for score, row in idx.search(query_vec, n)]
+            res = idx.search(query_vec, n)
+            return [(score, int(lookup.arr[row])) for score, row in res]
         finally:
             idx.release()
 
@@ -119,7 +193,8 @@ class DeviceEmbeddingsMatrix:
         idx, lookup = self.hold()
         try:
             scores, rows = idx.search_batch(query_vecs, n)
-            return [[(float(s), int(lookup[r])) for s, r in zip(scores[i], rows[i])] for i in range(len(scores))]
+            arr = lookup.arr
+            return [[(float(s), int(arr[r])) for s, r in zip(scores[i], rows[i])] for i in range(len(scores))]
         finally:
             idx.release()
 
@@ -128,15 +203,17 @@ class DeviceEmbeddingsMatrix:
         [(score, emb_id_1, emb_id_2)]."""
         idx, lookup = self.hold()
         try:
-            return [(score, int(lookup[i]), int(lookup[j])) for score, i, j in idx.top_pairs(n)]
+            res = idx.top_pairs(n)
+            return [(score, int(lookup.arr[i]), int(lookup.arr[j])) for score, i, j in res]
         finally:
             idx.release()
 
-    def hold(self) -> Tuple[Any, np.ndarray]:
-        """(index, lookup) with the caller owning a reference to the index, so a
-        concurrent ``invalidate()`` cannot free it mid-search.  Release it."""
+    def hold(self) -> Tuple[Any, _Lookup]:
+        """(index, lookup table) with the caller owning a reference to the index, so a
+        concurrent ``invalidate()`` cannot free it mid-search.  Map rows through
+        ``lookup.arr`` AFTER the search returns; release the index."""
         with self._mu:
-            idx, lookup = self.index, self.emb_id_lookup
+            idx, lookup = self.index, self._lookup
             if idx is None or lookup is None:
                 raise RuntimeError("embeddings matrix is not loaded (call get_sync/get first)")
             return idx.share(), lookup

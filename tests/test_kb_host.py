@@ -71,6 +71,56 @@ def test_document_top_pairwise_scores(tmp_path):
     kb.close()
 
 
+def test_incremental_add_and_delete_edit_the_loaded_matrix(tmp_path):
+    """bulk_add_docs / bulk_del_docs on a LOADED KB append / tombstone rows of the
+    HBM copy instead of dropping it; results must equal a KB
+    rebuilt from storage."""
+    rng = np.random.default_rng(12)
+    vecs = rng.standard_normal((300, 24)); vecs /= np.linalg.norm(vecs, axis=1, keepdims=True)
+    table = {f"doc {i}": [float(x) for x in vecs[i]] for i in range(300)}
+
+    async def ef(texts):
+        return [table[t] for t in texts]
+
+    path = str(tmp_path / "inc.sqlite")
+    kb = svs_amd.KB(path, ef, index_factory=OracleIndex)
+    with kb.bulk_add_docs() as add_doc:
+        for i in range(100):
+            add_doc(f"doc {i}")
+    kb.load()
+    first_index = kb.embeddings_matrix.index
+    with kb.bulk_add_docs() as add_doc:                 # append
+        for i in range(100, 180):
+            add_doc(f"doc {i}")
+    assert kb.embeddings_matrix.index is first_index and first_index.shape[0] == 180
+    with kb.bulk_del_docs() as del_doc:                 # tombstone (doc id == i + 1)
+        for i in (3, 50, 120, 179):
+            del_doc(i + 1)
+    assert kb.embeddings_matrix.index is first_index     # still the same HBM copy
+    with kb.bulk_add_docs() as add_doc:
+        add_doc("doc 200")
+    fresh = svs_amd.KB(path, ef, index_factory=OracleIndex)   # rebuilt from storage
+    for q in ("doc 3", "doc 120", "doc 200", "doc 17", "doc 250"):
+        a, b = kb.retrieve(q, 12), fresh.retrieve(q, 12)
+        assert [(d["doc"]["id"], d["score"]) for d in a] == [(d["doc"]["id"], d["score"]) for d in b], q
+    assert len(kb.retrieve("doc 1", 1000)) == 177
+    assert [(s, a["id"], b["id"]) for s, a, b in kb.document_top_pairwise_scores(20)] == \
+           [(s, a["id"], b["id"]) for s, a, b in fresh.document_top_pairwise_scores(20)]
+    # a failed transaction leaves storage untouched and simply drops the cache
+    with pytest.raises(KeyError):
+        with kb.bulk_del_docs() as del_doc:
+            del_doc(5); del_doc(99999)
+    assert [d["doc"]["id"] for d in kb.retrieve("doc 4", 3)] == [d["doc"]["id"] for d in fresh.retrieve("doc 4", 3)]
+    # many deletes trigger compaction (rebuild) instead of ever more tombstones
+    with kb.bulk_del_docs() as del_doc:
+        for i in range(60, 110):
+            del_doc(i + 1)
+    fresh.close(); fresh = svs_amd.KB(path, ef, index_factory=OracleIndex)
+    assert [d["doc"]["id"] for d in kb.retrieve("doc 70", 5)] == [d["doc"]["id"] for d in fresh.retrieve("doc 70", 5)]
+    kb.close(); fresh.close()
+    assert OracleIndex.live == 0
+
+
 def test_matrix_build_kat(tmp_path):
     """A7: BLOB rows -> (matrix, lookup), non-contiguous ids after a delete
     (reference tests/test_kb.py:753-806)."""
@@ -124,7 +174,7 @@ def test_invalidate_while_search_in_flight():
     cache.get_sync(None)
     idx, lookup = cache.hold()
     cache.invalidate()
-    assert [int(lookup[r]) for _, r in idx.search(m[2], 1)] == [30]
+    assert [int(lookup.arr[r]) for _, r in idx.search(m[2], 1)] == [30]
     idx.release()
     assert OracleIndex.live == 0
     with pytest.raises(RuntimeError):
