@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--dim", type=int, default=1536)
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--dtype", choices=["f32", "f16", "fp8"], default="f32",
+                    help="HBM element type of the corpus (f32 = the metric's config; f16/fp8 = BASELINE configs[2..4])")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -101,10 +103,11 @@ def main():
     # ---- synthetic corpus straight into HBM, then into the index's own layout
     rows = gen_rows(torch, dev, args.seed, lo, hi, d)
     torch.cuda.synchronize()
-    idx = DeviceIndex.from_device_pointer(rows.data_ptr(), n_local, d, device=local_rank, row_offset=lo)
+    idx = DeviceIndex.from_device_pointer(rows.data_ptr(), n_local, d, device=local_rank, row_offset=lo,
+                                          dtype=args.dtype)
     if args.variant:
         idx.set_variant(args.variant)
-    keep_rows_for_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    keep_rows_for_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and args.dtype == "f32"
     if not keep_rows_for_cpu:
         del rows
         torch.cuda.empty_cache()
@@ -234,21 +237,22 @@ def main():
             idx.search_batch(qb, k)
         dt = time.perf_counter() - a
         b_score, b_sel, b_cnt = idx.get_timing()
-        passes = (B + 15) // 16
+        passes = (B + 15) // 16 if args.dtype == "f32" else 1
         batched = {"queries_per_call": B, "value": B * reps / dt, "unit": "queries/s",
                    "ms_per_call": dt / reps * 1e3, "score_ms": b_score / max(b_cnt, 1), "select_ms": b_sel / max(b_cnt, 1),
                    "corpus_passes_per_call": passes,
-                   "corpus_GBps": float(n_local) * d * 4 * passes / (b_score / max(b_cnt, 1) * 1e-3) / 1e9,
+                   "corpus_GBps": float(n_local) * d * {"f32": 4, "f16": 2, "fp8": 1}[args.dtype] * passes / (b_score / max(b_cnt, 1) * 1e-3) / 1e9,
                    "note": "host API (queries in, results out, synchronised); exact f32 on v_mfma_f32_16x16x4_f32"}
     idx.set_timing(False)
 
     out = None
     if rank == 0:
         kernel_ms = score_ms / max(launches, 1)
-        alg_bytes = float(n_local) * d * 4
+        esz = {"f32": 4, "f16": 2, "fp8": 1}[args.dtype]
+        alg_bytes = float(n_local) * d * esz + (4.0 * n_local if args.dtype == "fp8" else 0.0)
         achieved = alg_bytes / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0
         out = {
-            "metric": "queries/sec, cosine top-%d over %dx%d fp32, single query" % (k, n_total, d),
+            "metric": "queries/sec, cosine top-%d over %dx%d %s, single query" % (k, n_total, d, {"f32": "fp32", "f16": "fp16", "fp8": "fp8"}[args.dtype]),
             "value": K / elapsed,
             "unit": "queries/s",
             "n_gpus": world,
@@ -258,11 +262,12 @@ def main():
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.dtype,
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE.json configs[1]: %d docs x dim %d fp32, top-%d, single query, "
-                            "HBM-resident GEMV + top-k%s" % (n_total, d, k, "" if world == 1 else ", row-sharded over %d GPUs + RCCL all-gather + host merge" % world),
+                "workload": ("BASELINE.json configs[1]: " if (args.dtype == "f32" and n_total == 1_000_000 and d == 1536) else "") +
+                            "%d docs x dim %d " % (n_total, d) + args.dtype + ", top-%d, single query, " % k +
+                            "HBM-resident GEMV + top-k" + ("" if world == 1 else ", row-sharded over %d GPUs + RCCL all-gather + host merge" % world),
                 "rows_per_gpu": n_local, "dim": d, "k": k, "queries_per_step": 1,
                 "corpus": "unit-norm gaussian, seed %d, generated on device" % args.seed,
                 "variant": args.variant, "searches_in_flight": len(streams),
@@ -281,7 +286,7 @@ def main():
         }
 
     # ---- CPU baseline: the numpy restatement of the reference path, this host's cores
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.dtype == "f32":
         from oracle import svs_oracle as oracle  # cpu_baseline leg only (checker + baseline)
         m_host = rows.cpu().numpy()
         del rows

@@ -103,16 +103,20 @@ __device__ __forceinline__ float dot16_fp8(u32x4_t a, const v4f* q, float acc) {
 
 // ---- single query, hot kernel: one-shot grid, R rows per wave (gemv_f32.h geometry)
 // A row of ld8 = NSTEP * 64 * LB bytes is NSTEP wave-wide loads of LB (16 or 8)
-// bytes per lane; the quantised query sits in NSTEP * LB f32 registers per lane.
+// bytes per lane.
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 
 template <int LB> struct Fp8Chunk;
 template <> struct Fp8Chunk<16> { typedef u32x4_t type; };
 template <> struct Fp8Chunk<8> { typedef u32x2_t type; };
 
+// The query stays PACKED (e4m3, LB bytes per lane per step) and is converted next
+// to the row bytes: 4x fewer registers than holding it as f32, which is what lets
+// two 16-wave workgroups share a CU (the kernel is HBM-bound; the extra
+// v_cvt_pk_f32_fp8 are free).
 template <int NSTEP, int LB, int R, int WPB>
 __global__ __launch_bounds__(WPB * 64) void gemv_fp8_oneshot_kernel(
-    const uint8_t* __restrict__ M, const float* __restrict__ row_scales, const float* __restrict__ qf,
+    const uint8_t* __restrict__ M, const float* __restrict__ row_scales, const uint8_t* __restrict__ q8,
     const float* __restrict__ q_scale, float* __restrict__ scores, int64_t n) {
   typedef typename Fp8Chunk<LB>::type chunk_t;
   constexpr int NW = LB / 4;               // 32-bit words per lane per load
@@ -130,16 +134,9 @@ __global__ __launch_bounds__(WPB * 64) void gemv_fp8_oneshot_kernel(
 #pragma unroll
     for (int j = 0; j < NSTEP; ++j) buf[r][j] = __builtin_nontemporal_load(p + j * 64);
   }
-  float qv[NSTEP][LB];
+  chunk_t qv[NSTEP];
 #pragma unroll
-  for (int j = 0; j < NSTEP; ++j) {
-    const v4f* qp = (const v4f*)(qf + (int64_t)(j * 64 + lane) * LB);
-#pragma unroll
-    for (int w = 0; w < NW; ++w) {
-      const v4f t = qp[w];
-      qv[j][4 * w + 0] = t.x; qv[j][4 * w + 1] = t.y; qv[j][4 * w + 2] = t.z; qv[j][4 * w + 3] = t.w;
-    }
-  }
+  for (int j = 0; j < NSTEP; ++j) qv[j] = ((const chunk_t*)q8)[j * 64 + lane];
   const float sq = q_scale[0];
   float out = 0.f;
 #pragma unroll
@@ -147,15 +144,24 @@ __global__ __launch_bounds__(WPB * 64) void gemv_fp8_oneshot_kernel(
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
     for (int j = 0; j < NSTEP; ++j) {
+      uint32_t aw[NW], qw[NW];
+      if constexpr (NW == 4) {
+        aw[0] = buf[r][j].x; aw[1] = buf[r][j].y; aw[2] = buf[r][j].z; aw[3] = buf[r][j].w;
+        qw[0] = qv[j].x; qw[1] = qv[j].y; qw[2] = qv[j].z; qw[3] = qv[j].w;
+      } else {
+        aw[0] = buf[r][j].x; aw[1] = buf[r][j].y;
+        qw[0] = qv[j].x; qw[1] = qv[j].y;
+      }
 #pragma unroll
       for (int w = 0; w < NW; ++w) {
-        float v[4];
-        unpack_fp8x4(buf[r][j][w], v);
+        float v[4], u[4];
+        unpack_fp8x4(aw[w], v);
+        unpack_fp8x4(qw[w], u);
         float& acc = (w & 1) ? s1 : s0;
-        acc = fmaf(v[0], qv[j][4 * w + 0], acc);
-        acc = fmaf(v[1], qv[j][4 * w + 1], acc);
-        acc = fmaf(v[2], qv[j][4 * w + 2], acc);
-        acc = fmaf(v[3], qv[j][4 * w + 3], acc);
+        acc = fmaf(v[0], u[0], acc);
+        acc = fmaf(v[1], u[1], acc);
+        acc = fmaf(v[2], u[2], acc);
+        acc = fmaf(v[3], u[3], acc);
       }
     }
     int64_t row = row0 + r;

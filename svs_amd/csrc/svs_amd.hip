@@ -328,16 +328,18 @@ int launch_scores(const svs_index* idx, Ctx* c, const float* q, float* scores, h
   do {                                                                                                          \
     const int64_t blocks = (idx->n + (R) * 16 - 1) / ((R) * 16);                                                \
     hipLaunchKernelGGL((gemv_fp8_oneshot_kernel<NSTEP, LB, R, 16>), dim3((unsigned)blocks), dim3(16 * 64), 0, st, \
-                       (const uint8_t*)idx->rows, idx->row_scales, (const float*)c->q8f, c->q8s, scores, idx->n);   \
+                       (const uint8_t*)idx->rows, idx->row_scales, (const uint8_t*)c->q8, c->q8s, scores, idx->n);     \
     return SVS_OK;                                                                                              \
   } while (0)
     switch (idx->ld) {
-      case 1024: SVS_FP8_HOT(1, 16, 4);
-      case 2048: SVS_FP8_HOT(2, 16, 2);
-      case 3072: SVS_FP8_HOT(3, 16, 2);
+      // one row per wave: with R > 1 hipcc keeps the converted query in f32 registers
+      // (84 VGPRs, one workgroup per CU); R = 1 converts it next to the row (<= 64 VGPRs)
+      case 1024: SVS_FP8_HOT(1, 16, 1);
+      case 2048: SVS_FP8_HOT(2, 16, 1);
+      case 3072: SVS_FP8_HOT(3, 16, 1);
       case 4096: SVS_FP8_HOT(4, 16, 1);
-      case 512: SVS_FP8_HOT(1, 8, 4);
-      case 1536: SVS_FP8_HOT(3, 8, 2);
+      case 512: SVS_FP8_HOT(1, 8, 1);
+      case 1536: SVS_FP8_HOT(3, 8, 1);
       default: break;
     }
 #undef SVS_FP8_HOT
