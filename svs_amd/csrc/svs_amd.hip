@@ -338,8 +338,8 @@ int launch_scores(const svs_index* idx, Ctx* c, const float* q, float* scores, h
       case 2048: SVS_FP8_HOT(2, 16, 1);
       case 3072: SVS_FP8_HOT(3, 16, 1);
       case 4096: SVS_FP8_HOT(4, 16, 1);
-      case 512: SVS_FP8_HOT(1, 8, 1);
-      case 1536: SVS_FP8_HOT(3, 8, 1);
+      case 512: SVS_FP8_HOT(1, 8, 4);    // 8-byte loads: several rows per wave keep enough bytes in flight
+      case 1536: SVS_FP8_HOT(3, 8, 2);
       default: break;
     }
 #undef SVS_FP8_HOT

@@ -17,7 +17,7 @@ __global__ void fill_kernel(float* p, size_t n, uint32_t seed) {
   }
 }
 
-struct Cfg { const char* name; int R, WPB; bool NT, CONTIG; void (*fn)(const v4f*, const v4f*, float*, int64_t, FuseArgs); };
+struct Cfg { const char* name; int R, WPB; bool NT, CONTIG; void (*fn)(const v4f*, const v4f*, float*, int64_t); };
 #define O(R, WPB, NT, QL) Cfg{"one" #R "r" #WPB "w" #NT "n" #QL "q", R, WPB, NT, false, gemv_f32_oneshot_kernel<6, R, WPB, NT, QL>}
 #define K(R, WPB, NT, CG) Cfg{#R "r" #WPB "w" #NT "n" #CG "c", R, WPB, NT, CG, gemv_f32_rows_kernel<6, R, WPB, NT, CG>}
 
