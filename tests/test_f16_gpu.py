@@ -20,7 +20,7 @@ def test_f16_single_query(gpu, n, d, k):
     from svs_amd import DeviceIndex
     m, qs = corpus_and_query("gaussian", 500 + n, n, d, 3)
     idx = DeviceIndex(m, dtype="f16")
-    assert idx.dtype == "f16" and idx.hbm_bytes == n * ((d + 7) // 8 * 8) * 2
+    assert idx.dtype == "f16" and idx.ld % 8 == 0 and idx.ld >= d and idx.hbm_bytes == n * idx.ld * 2
     md = _deq(m)
     for q in qs:
         qd = _deq(q)

@@ -34,7 +34,7 @@ def test_fp8_single_query(gpu, n, d, k):
     from svs_amd import DeviceIndex
     m, qs = corpus_and_query("gaussian", 300 + n, n, d, 3)
     idx = DeviceIndex(m, dtype="fp8")
-    assert idx.dtype == "fp8" and idx.hbm_bytes == n * ((d + 15) // 16 * 16) + 4 * n
+    assert idx.dtype == "fp8" and idx.ld % 16 == 0 and idx.ld >= d and idx.hbm_bytes == n * idx.ld + 4 * n
     md = idx.stored_rows()
     for q in qs:
         qd = idx.stored_query(q)
