@@ -237,7 +237,7 @@ def main():
             idx.search_batch(qb, k)
         dt = time.perf_counter() - a
         b_score, b_sel, b_cnt = idx.get_timing()
-        passes = (B + 15) // 16 if args.dtype == "f32" else 1
+        passes = (1 if B <= 16 else (B + 31) // 32) if args.dtype == "f32" else 1
         batched = {"queries_per_call": B, "value": B * reps / dt, "unit": "queries/s",
                    "ms_per_call": dt / reps * 1e3, "score_ms": b_score / max(b_cnt, 1), "select_ms": b_sel / max(b_cnt, 1),
                    "corpus_passes_per_call": passes,

@@ -1,4 +1,5 @@
-// Score stage, up to 16 queries per corpus pass, f32 corpus, exact f32 math:
+// Score stage, up to 16 queries per corpus pass, f32 corpus, exact f32 math
+// (batches of more than 16 queries take gemm_tiled.h with EB = 4, 32 per pass):
 //     scores[j][i] = sum_d M[i,d] * Q[j,d]        j < 16
 // The reference has no batched entry (a batch is a loop of np.dot calls,
 // src/svs/kb.py:1623); this kernel amortises ONE read of the corpus over 16

@@ -2,8 +2,9 @@
 //     S[j][i] = sum_d M8/16[i,d] * Q8/16[j,d]   (f32 accumulate; x scales for fp8)
 // for BASELINE.json configs[2] (1M x 1536 f16, 1024 queries) and configs[4]
 // (10M x 3072 fp8, 256 queries).  EB = bytes per element: 2 -> half operands on
-// v_mfma_f32_16x16x32_f16, 1 -> e4m3 operands on v_mfma_f32_16x16x32_fp8_fp8 (a
-// k-step is always 128 BYTES per row: 64 halves or 128 fp8).  The reference's
+// v_mfma_f32_16x16x32_f16, 1 -> e4m3 operands on v_mfma_f32_16x16x32_fp8_fp8,
+// 4 -> exact f32 on v_mfma_f32_16x16x4_f32, 16-32 queries per corpus pass (a
+// k-step is always 128 BYTES per row: 32 floats, 64 halves or 128 fp8).  The reference's
 // nearest analogue is its np.dot(M, M.T) (src/svs/kb.py:1651); a query batch is
 // by definition a loop of np.dot(M, q) calls (src/svs/kb.py:1623).
 //
@@ -173,6 +174,36 @@ __global__ __launch_bounds__(TG_WAVES * 64) void gemm_tiled_kernel(
 #pragma unroll
           for (int j = 0; j < NT; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+    } else if constexpr (EB == 4) {
+      // exact f32: v_mfma_f32_16x16x4_f32 (bit-for-bit an fmaf chain).  A 128-byte stage is 32
+      // floats per row; lane (r16, g) takes chunk 4t + g of sub-step t and its four components
+      // feed four MFMAs whose k-slot g maps to column 16t + 4g + e -- the same map for both
+      // operands, so the permutation cancels.
+      const v4f* A4 = (const v4f*)A;
+      const v4f* B4 = (const v4f*)B;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        v4f fa[MT], fb[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int r = wm * TM + i * 16 + r16;
+          fa[i] = A4[r * 8 + ((4 * t + g) ^ tg_swz(r))];
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int r = wn * TN + j * 16 + r16;
+          fb[j] = B4[r * 8 + ((4 * t + g) ^ tg_swz(r))];
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+          }
       }
     } else {
       const long* A8 = (const long*)A;

@@ -453,6 +453,7 @@ int launch_scores_q16(const svs_index* idx, Ctx* c, const float* q_dev, int nq_g
 // ---- LDS-tiled MFMA GEMM, f16 / fp8 corpus (gemm_tiled.h) ----------------------
 bool tiled_ok(const svs_index* idx) {
   if (idx->variant.load() == 7) return false;
+  if (idx->dtype == SVS_DTYPE_F32) return (idx->ld * 4) % TG_BKB == 0 && idx->variant.load() != 5;
   if (idx->dtype == SVS_DTYPE_F16) return (idx->ld * 2) % TG_BKB == 0;
   if (idx->dtype == SVS_DTYPE_FP8) return idx->ld % TG_BKB == 0;
   return false;
@@ -475,7 +476,7 @@ int launch_tiled_bn(const svs_index* idx, Ctx* c, int64_t n_rows, int nq, float*
                               (int)((3 * TG_BM * 8 + 3 * BN * 8) * sizeof(u32x4)));
   });
   const unsigned gx = (unsigned)((n_rows + TG_BM - 1) / TG_BM), gy = (unsigned)((nq + BN - 1) / BN);
-  const uint8_t* Q = EB == 2 ? (const uint8_t*)c->qh : (const uint8_t*)c->q8;
+  const uint8_t* Q = EB == 2 ? (const uint8_t*)c->qh : (EB == 1 ? (const uint8_t*)c->q8 : (const uint8_t*)c->q16);
   hipLaunchKernelGGL((gemm_tiled_kernel<BN, FUSE, EB>), dim3(gx, gy), dim3(TG_WAVES * 64), lds, st,
                      (const uint8_t*)idx->rows, Q, scores, n_rows, (int64_t)idx->ld * EB, sstride, nq,
                      fl.state, (int)SCR_WORDS, fl.cand, (uint32_t)CAND_CAP, fl.thr, fl.thr_stride,
@@ -498,6 +499,22 @@ int launch_tiled_eb(const svs_index* idx, Ctx* c, int64_t n_rows, int nq, int bn
 // rows [0, n_rows) of the corpus; restage == false reuses the quantised queries already staged in the context
 int launch_scores_tiled(const svs_index* idx, Ctx* c, const float* q_dev, int64_t n_rows, int nq, float* scores,
                         int64_t sstride, FuseLaunch fl, hipStream_t st, bool restage = true) {
+  if (idx->dtype == SVS_DTYPE_F32) {
+    // exact-f32 MFMA runs at the vector rate: 32 queries per pass keep the kernel HBM-bound
+    // (62 % of the matrix pipe); larger batches loop passes.
+    const int bn = nq <= 16 ? 32 : 32;
+    for (int q0 = 0; q0 < nq; q0 += bn) {
+      const int nq_g = std::min(bn, nq - q0);
+      int rc = grow_dev(&c->q16, &c->q16_cap, (size_t)bn * idx->ld);
+      if (rc != SVS_OK) return rc;
+      HIP_TRY(hipMemsetAsync(c->q16, 0, (size_t)bn * idx->ld * sizeof(float), st));
+      HIP_TRY(hipMemcpy2DAsync(c->q16, (size_t)idx->ld * sizeof(float), q_dev + (size_t)q0 * idx->d, (size_t)idx->d * sizeof(float),
+                               (size_t)idx->d * sizeof(float), (size_t)nq_g, hipMemcpyDeviceToDevice, st));
+      rc = launch_tiled_bn<32, false, 4>(idx, c, n_rows, nq_g, scores + (size_t)q0 * sstride, sstride, FuseLaunch{}, st);
+      if (rc != SVS_OK) return rc;
+    }
+    return SVS_OK;
+  }
   const int bn = nq <= 32 ? 32 : (nq <= 64 ? 64 : (nq <= 128 ? 128 : 256));
   const int nq_pad = (nq + bn - 1) / bn * bn;
   if (restage) {
@@ -551,7 +568,9 @@ int run_select(svs_index* idx, Ctx* c, const float* scores, int64_t n_eff, int64
 // Materialised scores of nq queries: scores[q][sstride] (the non-fused score stage).
 int launch_scores_any(svs_index* idx, Ctx* c, const float* q_dev, int nq, float* scores, int64_t sstride, hipStream_t st) {
   int rc;
-  if (nq >= 2 && batch_kernel_ok(idx)) {
+  // f32: up to 16 queries -> the 16-query streaming kernel (5.4 TB/s, 1.14 ms at 1M x 1536);
+  // more -> the tiled kernel at 32 queries per pass (1.30 ms: bound by the f32 MFMA rate)
+  if (nq >= 2 && batch_kernel_ok(idx) && (nq <= GQ || idx->variant.load() == 5 || !tiled_ok(idx))) {
     for (int q0 = 0; q0 < nq; q0 += GQ) {
       rc = launch_scores_q16(idx, c, q_dev + (size_t)q0 * idx->d, std::min(GQ, nq - q0), scores + (size_t)q0 * sstride, sstride, st);
       if (rc != SVS_OK) return rc;
@@ -581,6 +600,7 @@ int enqueue_search(svs_index* idx, Ctx* c, const float* q_dev, int nq, int k, in
   // Fused top-k epilogue (no score matrix): batched f16 GEMM only; a query whose
   // candidate list overflows comes back marked and is re-run by the caller.
   const bool fused = allow_fused && path_a && nq >= 64 && n >= 8 * FUSE_PREFIX_MIN && tiled_ok(idx) &&
+                     idx->dtype != SVS_DTYPE_F32 &&
                      count <= 256 && idx->dead_list.empty() && idx->variant.load() != 6;
   const int64_t n_mat = fused ? fuse_prefix_rows(n) : n;     // rows of the materialised score matrix
   const int64_t sstride = (n_mat + 3) & ~(int64_t)3;         // float4-aligned score vectors
