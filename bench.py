@@ -69,7 +69,8 @@ def main():
     ap.add_argument("--latency-iters", type=int, default=200)
     ap.add_argument("--gather-every", type=int, default=8,
                     help="N > 1: steps whose local top-k records share one RCCL all-gather")
-    ap.add_argument("--batch", type=int, default=16, help="queries per call of the secondary batched figure (0: skip)")
+    ap.add_argument("--batch", default="16,256",
+                    help="queries per call of the secondary batched figures, comma separated (0: skip)")
     ap.add_argument("--inflight", type=int, default=1,
                     help="searches kept in flight on separate HIP streams (2 lets the top-k "
                          "stage of query i overlap the score stage of query i+1)")
@@ -225,24 +226,27 @@ def main():
     # ---- secondary figure (N = 1 only; not `value`): batched search, 16 queries
     # share one pass over the corpus (north_star: >= 10,000 queries/s at 1 GPU)
     batched = None
-    if world == 1 and args.batch > 1:
-        B = args.batch
-        qb = queries[: B].cpu().numpy()
-        for _ in range(3):
-            idx.search_batch(qb, k)
-        idx.set_timing(True)
-        reps = 30
-        a = time.perf_counter()
-        for _ in range(reps):
-            idx.search_batch(qb, k)
-        dt = time.perf_counter() - a
-        b_score, b_sel, b_cnt = idx.get_timing()
-        passes = (1 if B <= 16 else (B + 31) // 32) if args.dtype == "f32" else 1
-        batched = {"queries_per_call": B, "value": B * reps / dt, "unit": "queries/s",
-                   "ms_per_call": dt / reps * 1e3, "score_ms": b_score / max(b_cnt, 1), "select_ms": b_sel / max(b_cnt, 1),
-                   "corpus_passes_per_call": passes,
-                   "corpus_GBps": float(n_local) * d * {"f32": 4, "f16": 2, "fp8": 1}[args.dtype] * passes / (b_score / max(b_cnt, 1) * 1e-3) / 1e9,
-                   "note": "host API (queries in, results out, synchronised); exact f32 on v_mfma_f32_16x16x4_f32"}
+    if world == 1 and args.batch:
+        batched = []
+        for B in [int(x) for x in str(args.batch).split(",") if int(x) > 1]:
+            gb = torch.Generator(device=dev)
+            gb.manual_seed(args.seed + 999 + B)
+            qb = torch.randn((B, d), device=dev, dtype=torch.float32, generator=gb)
+            qb = (qb / qb.norm(dim=1, keepdim=True)).cpu().numpy()
+            for _ in range(3):
+                idx.search_batch(qb, k)
+            idx.set_timing(True)
+            reps = max(3, min(30, 512 // B))
+            a = time.perf_counter()
+            for _ in range(reps):
+                idx.search_batch(qb, k)
+            dt = time.perf_counter() - a
+            b_score, b_sel, b_cnt = idx.get_timing()
+            idx.set_timing(False)
+            batched.append({"queries_per_call": B, "value": B * reps / dt, "unit": "queries/s",
+                            "ms_per_call": dt / reps * 1e3, "score_ms": b_score / max(b_cnt, 1),
+                            "select_ms": b_sel / max(b_cnt, 1),
+                            "note": "host API (queries in, results out, synchronised)"})
     idx.set_timing(False)
 
     out = None
