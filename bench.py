@@ -86,11 +86,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # SVS_BENCH_BACKEND=gloo (rehearsal only): lets several ranks share ONE card on a 1-GPU
+    # box to exercise the sharded code path end to end; the real run is RCCL, one GPU per rank.
+    backend = os.environ.get("SVS_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     d, k, K, W = args.dim, args.k, args.steps, args.warmup
     if args.scaling == "strong":
@@ -104,7 +111,7 @@ def main():
     # ---- synthetic corpus straight into HBM, then into the index's own layout
     rows = gen_rows(torch, dev, args.seed, lo, hi, d)
     torch.cuda.synchronize()
-    idx = DeviceIndex.from_device_pointer(rows.data_ptr(), n_local, d, device=local_rank, row_offset=lo,
+    idx = DeviceIndex.from_device_pointer(rows.data_ptr(), n_local, d, device=dev_index, row_offset=lo,
                                           dtype=args.dtype)
     if args.variant:
         idx.set_variant(args.variant)

@@ -37,7 +37,7 @@ namespace svs {
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-constexpr int TG_BM = 128;  // corpus rows per workgroup tile
+constexpr int TG_BM = 128;  // corpus rows per workgroup tile (256 for the MFMA-bound BN = 256 panels)
 constexpr int TG_BKB = 128;  // BYTES per row per k-step (one 128-byte line)
 constexpr int TG_WAVES = 8;
 
@@ -71,24 +71,34 @@ __device__ __forceinline__ void fuse_offer(uint32_t* hdr, uint64_t* cand, uint32
 // Every wave issues the SAME number of DMA instructions, max(1, rows/64) (with
 // fewer than 8 instructions in all, the surplus waves repeat one -- same bytes to
 // the same place), so a counted s_waitcnt vmcnt(N) means the same thing in every wave.
+// The per-lane source addresses of k-step 0 and the LDS slots are fixed for the whole
+// tile: they are computed once (TgSrc) and each stage only adds s * 128 bytes.
 template <int ROWS>
-__device__ __forceinline__ void tg_stage(const uint8_t* __restrict__ base, int64_t row0,
-                                         int64_t row_max, int64_t ldb, int s, u32x4* lds, int wave, int lane) {
-  constexpr int NI = ROWS / 8;                       // wave instructions in the tile
-  constexpr int PER = NI >= TG_WAVES ? NI / TG_WAVES : 1;
-  const int r_in = lane >> 3, pc = lane & 7;
+struct TgSrc {
+  static constexpr int NI = ROWS / 8;                       // wave instructions in the tile
+  static constexpr int PER = NI >= TG_WAVES ? NI / TG_WAVES : 1;
+  const uint8_t* src[PER];
+  int slot[PER];                                            // LDS offset of the instruction, in u32x4
+  __device__ __forceinline__ void init(const uint8_t* __restrict__ base, int64_t row0, int64_t row_max, int64_t ldb,
+                                       int wave, int lane) {
+    const int r_in = lane >> 3, pc = lane & 7;
 #pragma unroll
-  for (int t = 0; t < PER; ++t) {
-    const int i = (wave + t * TG_WAVES) % NI;
-    const int r = i * 8 + r_in;
-    int64_t gr = row0 + r;
-    gr = gr < row_max ? gr : row_max - 1;
-    const int gc = pc ^ tg_swz(r);
-    const uint8_t* src = base + gr * ldb + s * TG_BKB + gc * 16;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)(lds + i * 64), 16, 0, 0);
+    for (int t = 0; t < PER; ++t) {
+      const int i = (wave + t * TG_WAVES) % NI;
+      const int r = i * 8 + r_in;
+      int64_t gr = row0 + r;
+      gr = gr < row_max ? gr : row_max - 1;
+      src[t] = base + gr * ldb + (pc ^ tg_swz(r)) * 16;
+      slot[t] = i * 64;
+    }
   }
-}
+  __device__ __forceinline__ void stage(int s, u32x4* lds) const {
+#pragma unroll
+    for (int t = 0; t < PER; ++t)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[t] + (int64_t)s * TG_BKB),
+                                       (__attribute__((address_space(3))) void*)(lds + slot[t]), 16, 0, 0);
+  }
+};
 
 template <int ROWS> constexpr int tg_stage_count() { return ROWS / 8 >= TG_WAVES ? ROWS / 8 / TG_WAVES : 1; }
 
@@ -98,7 +108,10 @@ template <int ROWS> constexpr int tg_stage_count() { return ROWS / 8 >= TG_WAVES
 // the per-query header word fstate_words[q * fstate_stride].
 // ldb = row stride in BYTES (multiple of 128) of both M and Q.  EB == 1: the
 // accumulators are multiplied by rscale[row] * qscale[query] before use.
-template <int BN, bool FUSE, int EB>
+constexpr int tg_nbuf(int bm, int bn) { return 3 * (bm + bn) * 128 <= 160 * 1024 ? 3 : 2; }
+constexpr int tg_lds_bytes(int bm, int bn) { return tg_nbuf(bm, bn) * (bm + bn) * 128; }
+
+template <int BN, bool FUSE, int EB, int BM = TG_BM>
 __global__ __launch_bounds__(TG_WAVES * 64) void gemm_tiled_kernel(
     const uint8_t* __restrict__ M, const uint8_t* __restrict__ Q, float* __restrict__ scores,
     int64_t n, int64_t ldb, int64_t sstride, int nq, uint32_t* __restrict__ fstate_words, int fstate_stride,
@@ -107,21 +120,21 @@ __global__ __launch_bounds__(TG_WAVES * 64) void gemm_tiled_kernel(
   constexpr int TN = BN < 64 ? BN : 64;     // queries per wave tile
   constexpr int WN = BN / TN;               // waves along the query axis
   constexpr int WM = TG_WAVES / WN;         // waves along the row axis
-  constexpr int TM = TG_BM / WM;            // rows per wave tile
+  constexpr int TM = BM / WM;               // rows per wave tile
   constexpr int MT = TM / 16, NT = TN / 16; // MFMA tiles per wave
   static_assert(TM % 16 == 0 && TN % 16 == 0, "wave tile must be whole MFMA tiles");
   extern __shared__ u32x4 tg_lds[];
   // layout: A buffers [NBUF][128 rows][8 chunks], then B buffers [NBUF][BN rows][8 chunks]
-  constexpr int NBUF = 3;
-  auto ldsA = [&](int b) { return tg_lds + b * (TG_BM * 8); };
-  auto ldsB = [&](int b) { return tg_lds + NBUF * TG_BM * 8 + b * (BN * 8); };
-  constexpr int DMA_PER_STAGE = tg_stage_count<TG_BM>() + tg_stage_count<BN>();
+  constexpr int NBUF = tg_nbuf(BM, BN);   // 3 when it fits the 160 KiB LDS, else 2 (256 x 256 tiles)
+  auto ldsA = [&](int b) { return tg_lds + b * (BM * 8); };
+  auto ldsB = [&](int b) { return tg_lds + NBUF * BM * 8 + b * (BN * 8); };
+  constexpr int DMA_PER_STAGE = tg_stage_count<BM>() + tg_stage_count<BN>();
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int r16 = lane & 15, g = lane >> 4;
-  const int64_t row0 = (int64_t)blockIdx.x * TG_BM;
+  const int64_t row0 = (int64_t)blockIdx.x * BM;
   const int q0 = blockIdx.y * BN;
   const int ksteps = (int)(ldb / TG_BKB);
 
@@ -137,21 +150,27 @@ __global__ __launch_bounds__(TG_WAVES * 64) void gemm_tiled_kernel(
   // step's DMA retired) -> raw s_barrier -> issue step s+2 into the buffer that
   // was read in step s-1 (everyone is past that read: same barrier) -> multiply
   // step s.  A plain __syncthreads() would make hipcc drain vmcnt(0) every step.
-  tg_stage<TG_BM>(M, row0, n, ldb, 0, ldsA(0), wave, lane);
-  tg_stage<BN>(Q, q0, (int64_t)q0 + BN, ldb, 0, ldsB(0), wave, lane);
-  if (ksteps > 1) {
-    tg_stage<TG_BM>(M, row0, n, ldb, 1, ldsA(1), wave, lane);
-    tg_stage<BN>(Q, q0, (int64_t)q0 + BN, ldb, 1, ldsB(1), wave, lane);
+  TgSrc<BM> srcA;
+  TgSrc<BN> srcB;
+  srcA.init(M, row0, n, ldb, wave, lane);
+  srcB.init(Q, q0, (int64_t)q0 + BN, ldb, wave, lane);
+  constexpr int AHEAD = NBUF - 1;         // k-steps of DMA kept in flight
+  srcA.stage(0, ldsA(0));
+  srcB.stage(0, ldsB(0));
+  if (AHEAD > 1 && ksteps > 1) {
+    srcA.stage(1, ldsA(1));
+    srcB.stage(1, ldsB(1));
   }
   int cur = 0;
   for (int s = 0; s < ksteps; ++s) {
-    if (s + 1 < ksteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_STAGE) : "memory");
+    // retire step s's DMA: everything but the (AHEAD - 1) younger steps
+    if (AHEAD > 1 && s + 1 < ksteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_STAGE) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (s + 2 < ksteps) {
-      const int nb = cur >= 1 ? cur - 1 : NBUF - 1;   // (s + 2) % 3
-      tg_stage<TG_BM>(M, row0, n, ldb, s + 2, ldsA(nb), wave, lane);
-      tg_stage<BN>(Q, q0, (int64_t)q0 + BN, ldb, s + 2, ldsB(nb), wave, lane);
+    if (s + AHEAD < ksteps) {
+      const int nb = cur >= 1 ? cur - 1 : NBUF - 1;   // (s + AHEAD) % NBUF: the buffer read in step s - 1
+      srcA.stage(s + AHEAD, ldsA(nb));
+      srcB.stage(s + AHEAD, ldsB(nb));
     }
     const u32x4* A = ldsA(cur);
     const u32x4* B = ldsB(cur);

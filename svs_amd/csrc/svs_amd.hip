@@ -466,18 +466,18 @@ struct FuseLaunch {   // non-null state: fused top-k epilogue, no score matrix
   int thr_stride = 0;
 };
 
-template <int BN, bool FUSE, int EB>
+template <int BN, bool FUSE, int EB, int BM = TG_BM>
 int launch_tiled_bn(const svs_index* idx, Ctx* c, int64_t n_rows, int nq, float* scores, int64_t sstride,
                     FuseLaunch fl, hipStream_t st) {
   static std::once_flag once;
-  const size_t lds = (size_t)(3 * TG_BM * 8 + 3 * BN * 8) * sizeof(u32x4);
+  const size_t lds = (size_t)tg_lds_bytes(BM, BN);
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute((const void*)gemm_tiled_kernel<BN, FUSE, EB>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)((3 * TG_BM * 8 + 3 * BN * 8) * sizeof(u32x4)));
+    (void)hipFuncSetAttribute((const void*)gemm_tiled_kernel<BN, FUSE, EB, BM>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              tg_lds_bytes(BM, BN));
   });
-  const unsigned gx = (unsigned)((n_rows + TG_BM - 1) / TG_BM), gy = (unsigned)((nq + BN - 1) / BN);
+  const unsigned gx = (unsigned)((n_rows + BM - 1) / BM), gy = (unsigned)((nq + BN - 1) / BN);
   const uint8_t* Q = EB == 2 ? (const uint8_t*)c->qh : (EB == 1 ? (const uint8_t*)c->q8 : (const uint8_t*)c->q16);
-  hipLaunchKernelGGL((gemm_tiled_kernel<BN, FUSE, EB>), dim3(gx, gy), dim3(TG_WAVES * 64), lds, st,
+  hipLaunchKernelGGL((gemm_tiled_kernel<BN, FUSE, EB, BM>), dim3(gx, gy), dim3(TG_WAVES * 64), lds, st,
                      (const uint8_t*)idx->rows, Q, scores, n_rows, (int64_t)idx->ld * EB, sstride, nq,
                      fl.state, (int)SCR_WORDS, fl.cand, (uint32_t)CAND_CAP, fl.thr, fl.thr_stride,
                      (const float*)idx->row_scales, (const float*)c->q8s);
@@ -492,7 +492,11 @@ int launch_tiled_eb(const svs_index* idx, Ctx* c, int64_t n_rows, int nq, int bn
     case 32: return f ? launch_tiled_bn<32, true, EB>(idx, c, n_rows, nq, scores, sstride, fl, st) : launch_tiled_bn<32, false, EB>(idx, c, n_rows, nq, scores, sstride, fl, st);
     case 64: return f ? launch_tiled_bn<64, true, EB>(idx, c, n_rows, nq, scores, sstride, fl, st) : launch_tiled_bn<64, false, EB>(idx, c, n_rows, nq, scores, sstride, fl, st);
     case 128: return f ? launch_tiled_bn<128, true, EB>(idx, c, n_rows, nq, scores, sstride, fl, st) : launch_tiled_bn<128, false, EB>(idx, c, n_rows, nq, scores, sstride, fl, st);
-    default: return f ? launch_tiled_bn<256, true, EB>(idx, c, n_rows, nq, scores, sstride, fl, st) : launch_tiled_bn<256, false, EB>(idx, c, n_rows, nq, scores, sstride, fl, st);
+    default:
+      if (idx->variant.load() == 4)   // A/B: 128-row tiles, three-stage ring
+        return f ? launch_tiled_bn<256, true, EB>(idx, c, n_rows, nq, scores, sstride, fl, st) : launch_tiled_bn<256, false, EB>(idx, c, n_rows, nq, scores, sstride, fl, st);
+      return f ? launch_tiled_bn<256, true, EB, 256>(idx, c, n_rows, nq, scores, sstride, fl, st)
+               : launch_tiled_bn<256, false, EB, 256>(idx, c, n_rows, nq, scores, sstride, fl, st);
   }
 }
 

@@ -10,6 +10,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 d = int(sys.argv[2]) if len(sys.argv) > 2 else 1536
 dtypes = sys.argv[3].split(",") if len(sys.argv) > 3 else ["f32", "f16", "fp8"]
 nqs = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else [1, 16, 32, 64, 256, 1024]
+variant = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev); g.manual_seed(1)
 blk = 500_000
@@ -29,6 +30,7 @@ for dtype in dtypes:
         big = torch.cat(shards); del shards, m
         idx = DeviceIndex.from_device_pointer(big.data_ptr(), n, d, device=0, dtype=dtype); del big
     torch.cuda.empty_cache()
+    idx.set_variant(variant)
     for nq in nqs:
         qs = torch.randn((nq, d), device=dev, generator=g); qs /= qs.norm(dim=1, keepdim=True)
         qh = qs.cpu().numpy()
