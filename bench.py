@@ -202,6 +202,23 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- rehearsal check (SVS_BENCH_VERIFY=1, N > 1): the merged result of the sharded run must
+    # be IDENTICAL (rows and score bits) to one index over the whole corpus -- the kernels'
+    # summation order does not depend on where a row lives
+    sharded_check = None
+    if world > 1 and rank == 0 and os.environ.get("SVS_BENCH_VERIFY"):
+        whole_rows = gen_rows(torch, dev, args.seed, 0, n_total if args.scaling == "strong" else args.rows * world, d)
+        whole = DeviceIndex.from_device_pointer(whole_rows.data_ptr(), whole_rows.shape[0], d, device=dev_index, dtype=args.dtype)
+        del whole_rows
+        bad = 0
+        for j in range(min(16, K)):
+            exp = whole.search(queries[W + j].cpu().numpy(), k)
+            got_s, got_r = results[j]
+            if [int(x) for x in got_r] != [r for _, r in exp] or [float(x) for x in got_s] != [sc for sc, _ in exp]:
+                bad += 1
+        whole.release()
+        sharded_check = {"queries": min(16, K), "mismatches": bad}
+
     # ---- p50 latency at the C-ABI boundary (host buffers in, results out, synced)
     lat_ms = None
     if world == 1:
@@ -285,6 +302,7 @@ def main():
                 "steps_per_exchange": G if world > 1 else None,
             },
             "p50_latency_ms": lat_ms,
+            "sharded_check": sharded_check,
             "batched": batched,
             "stage_ms": {"score": kernel_ms, "select": select_ms / max(launches, 1)},
             "roofline": {
