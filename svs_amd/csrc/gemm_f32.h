@@ -40,7 +40,7 @@ constexpr int GEMM_WAVES = 8;
 constexpr int GEMM_PF = 8;    // k-steps prefetched per tile half
 
 // Q16: [16][ld] f32 (rows >= nq zero).  scores: [16][sstride].
-template <bool NT>
+template <bool NT, int TILES = 2, int PF = GEMM_PF>
 __global__ __launch_bounds__(GEMM_WAVES * 64) void gemm_f32_q16_kernel(
     const float* __restrict__ M, const float* __restrict__ Q16, float* __restrict__ scores,
     int64_t n, int ld, int64_t sstride, int nq, int rows_per_block) {
@@ -58,61 +58,64 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void gemm_f32_q16_kernel(
   const int64_t blk0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t blk1 = blk0 + rows_per_block < n ? blk0 + rows_per_block : n;
   const int r16 = lane & 15, g = lane >> 4;
-  for (int64_t row0 = blk0 + wave * 32; row0 < blk1; row0 += GEMM_WAVES * 32) {
-    int64_t ra = row0 + r16, rb = row0 + 16 + r16;
-    ra = ra < n ? ra : n - 1;  // clamp: never read past the matrix
-    rb = rb < n ? rb : n - 1;
-    const v4f* pa = (const v4f*)(M + ra * ld + 4 * g);
-    const v4f* pb = (const v4f*)(M + rb * ld + 4 * g);
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    v4f a0[GEMM_PF], a1[GEMM_PF];
+  constexpr int TROWS = 16 * TILES;
+  for (int64_t row0 = blk0 + wave * TROWS; row0 < blk1; row0 += GEMM_WAVES * TROWS) {
+    const v4f* p[TILES];
+    f32x4 acc[TILES];
 #pragma unroll
-    for (int j = 0; j < GEMM_PF; ++j) {
-      a0[j] = ldg4<NT>(pa + 4 * j);   // step j: columns 16 j + 4 g .. +4  (v4f units: 4 per step)
-      a1[j] = ldg4<NT>(pb + 4 * j);
+    for (int t = 0; t < TILES; ++t) {
+      int64_t r = row0 + 16 * t + r16;
+      r = r < n ? r : n - 1;  // clamp: never read past the matrix
+      p[t] = (const v4f*)(M + r * ld + 4 * g);
+      acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    for (int s0 = 0; s0 < ksteps; s0 += GEMM_PF) {
-      v4f n0[GEMM_PF], n1[GEMM_PF];
-      const bool more = s0 + GEMM_PF < ksteps;
-      if (more) {
+    v4f a[TILES][PF];
 #pragma unroll
-        for (int j = 0; j < GEMM_PF; ++j) {
-          n0[j] = ldg4<NT>(pa + 4 * (s0 + GEMM_PF + j));
-          n1[j] = ldg4<NT>(pb + 4 * (s0 + GEMM_PF + j));
-        }
-      }
+    for (int t = 0; t < TILES; ++t)
 #pragma unroll
-      for (int j = 0; j < GEMM_PF; ++j) {
+      for (int j = 0; j < PF; ++j) a[t][j] = ldg4<NT>(p[t] + 4 * j);   // step j: columns 16 j + 4 g .. +4
+    auto mul_chunk = [&](int s0) {
+#pragma unroll
+      for (int j = 0; j < PF; ++j) {
         const v4f qf = qlds[(s0 + j) * 64 + lane];
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j].x, qf.x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j].x, qf.x, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j].y, qf.y, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j].y, qf.y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j].z, qf.z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j].z, qf.z, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j].w, qf.w, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j].w, qf.w, acc1, 0, 0, 0);
-      }
-      if (more) {
 #pragma unroll
-        for (int j = 0; j < GEMM_PF; ++j) {
-          a0[j] = n0[j];
-          a1[j] = n1[j];
-        }
+        for (int t = 0; t < TILES; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][j].x, qf.x, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][j].y, qf.y, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][j].z, qf.z, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][j].w, qf.w, acc[t], 0, 0, 0);
       }
+    };
+    // Steady state has NO conditional around the prefetch: a branch there makes hipcc wait
+    // for the just-issued loads at the join (the same trap as in gemv_f32.h); the last
+    // chunk is peeled instead.
+    int s0 = 0;
+    for (; s0 + PF < ksteps; s0 += PF) {
+      v4f nx[TILES][PF];
+#pragma unroll
+      for (int t = 0; t < TILES; ++t)
+#pragma unroll
+        for (int j = 0; j < PF; ++j) nx[t][j] = ldg4<NT>(p[t] + 4 * (s0 + PF + j));
+      mul_chunk(s0);
+#pragma unroll
+      for (int t = 0; t < TILES; ++t)
+#pragma unroll
+        for (int j = 0; j < PF; ++j) a[t][j] = nx[t][j];
     }
+    mul_chunk(s0);
     // D layout: column (query) = lane & 15, rows 4 g + r of the 16-row tile
     if (r16 < nq) {
       float* o = scores + (int64_t)r16 * sstride;
-      const int64_t oa = row0 + 4 * g, ob = row0 + 16 + 4 * g;
-      if (oa + 3 < blk1) *(f32x4*)(o + oa) = acc0;
-      else
-        for (int r = 0; r < 4; ++r)
-          if (oa + r < blk1) o[oa + r] = acc0[r];
-      if (ob + 3 < blk1) *(f32x4*)(o + ob) = acc1;
-      else
-        for (int r = 0; r < 4; ++r)
-          if (ob + r < blk1) o[ob + r] = acc1[r];
+#pragma unroll
+      for (int t = 0; t < TILES; ++t) {
+        const int64_t ob = row0 + 16 * t + 4 * g;
+        if (ob + 3 < blk1) *(f32x4*)(o + ob) = acc[t];
+        else
+          for (int r = 0; r < 4; ++r)
+            if (ob + r < blk1) o[ob + r] = acc[t][r];
+      }
     }
   }
 }

@@ -152,7 +152,9 @@ __global__ __launch_bounds__(WPB * 64) void gemv_f32_rows_kernel(
 // [b*WPB*R, (b+1)*WPB*R); wave w of it owns R consecutive rows.
 // QLDS: the query is staged once per workgroup in LDS and read back with
 // ds_read_b128 instead of each wave fetching it from L2.
-template <int NSTEP, int R, int WPB, bool NT, bool QLDS>
+// XCDMAP (experiment): workgroups are dealt round-robin over the 8 XCDs; with the remap
+// each XCD streams one contiguous eighth of the corpus instead of every eighth block.
+template <int NSTEP, int R, int WPB, bool NT, bool QLDS, bool XCDMAP = false>
 __global__ __launch_bounds__(WPB * 64) void gemv_f32_oneshot_kernel(
     const v4f* __restrict__ M, const v4f* __restrict__ q, float* __restrict__ scores,
     int64_t n) {
@@ -160,7 +162,12 @@ __global__ __launch_bounds__(WPB * 64) void gemv_f32_oneshot_kernel(
   __shared__ v4f qs[QLDS ? LD4 : 1];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t row0 = ((int64_t)blockIdx.x * WPB + wave) * R;
+  int64_t bid = blockIdx.x;
+  if constexpr (XCDMAP) {
+    const int64_t nb = gridDim.x, qd = nb / 8, rm = nb % 8, x = bid % 8;
+    bid = (x < rm ? x * (qd + 1) : rm * (qd + 1) + (x - rm) * qd) + bid / 8;   // bijective for any grid size
+  }
+  const int64_t row0 = (bid * WPB + wave) * R;
 
   v4f buf[R][NSTEP];
   if (row0 < n) {

@@ -441,7 +441,14 @@ int launch_scores_q16(const svs_index* idx, Ctx* c, const float* q_dev, int nq_g
   const int rows_per_block = variant == 4 ? 2048 : (variant == 5 ? 512 : 1024);
   const unsigned blocks = (unsigned)((idx->n + rows_per_block - 1) / rows_per_block);
   const size_t lds = (size_t)(ld / 16) * 64 * sizeof(v4f);
-  if (variant == 3)
+  if (variant == 3 && ld % 256 == 0) {   // A/B: one 16-row tile per wave, 16-step (1 KiB per row) bursts
+    static std::once_flag once2;
+    std::call_once(once2, [] {
+      (void)hipFuncSetAttribute((const void*)gemm_f32_q16_kernel<false, 1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 2304 * 64);
+    });
+    hipLaunchKernelGGL((gemm_f32_q16_kernel<false, 1, 16>), dim3(blocks), dim3(GEMM_WAVES * 64), lds, st,
+                       (const float*)idx->rows, q16, scores, idx->n, ld, sstride, nq_g, rows_per_block);
+  } else if (variant == 2)
     hipLaunchKernelGGL((gemm_f32_q16_kernel<true>), dim3(blocks), dim3(GEMM_WAVES * 64), lds, st,
                        (const float*)idx->rows, q16, scores, idx->n, ld, sstride, nq_g, rows_per_block);
   else

@@ -241,3 +241,23 @@ def test_select_window_fallbacks(gpu):
         for k in (1, 100, 1000, 2048):
             assert idx.search(q, k) == oracle.total_order_top_k(v, k), (name, k)
         idx.release()
+
+
+def test_no_hbm_leak_over_index_lifetimes(gpu):
+    """create / search / release in a loop must give the HBM back (contexts, scratch,
+    staging buffers and the corpus are all owned by the handle)."""
+    import torch
+    from svs_amd import DeviceIndex
+    m, qs = corpus_and_query("gaussian", 1, 40000, 512, 20)
+    free0 = None
+    for it in range(12):
+        idx = DeviceIndex(m, dtype=("f32", "f16", "fp8")[it % 3])
+        idx.search(qs[0], 10)
+        idx.search_batch(qs, 10)
+        idx.top_pairs(5) if it == 0 else None
+        idx.release()
+        torch.cuda.synchronize()
+        free, _ = torch.cuda.mem_get_info()
+        if it == 2:
+            free0 = free
+    assert free0 - free < 64 << 20, f"HBM shrank by {(free0 - free) >> 20} MiB over 9 index lifetimes"

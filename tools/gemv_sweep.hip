@@ -25,11 +25,11 @@ int main(int argc, char** argv) {
   int64_t n = argc > 1 ? atoll(argv[1]) : 1000000; const int d = 1536; int iters = argc > 2 ? atoi(argv[2]) : 20;
   float *M, *q, *s; CK(hipMalloc(&M, (size_t)n * d * 4)); CK(hipMalloc(&q, d * 4)); CK(hipMalloc(&s, n * 4));
   fill_kernel<<<4096, 256>>>(M, (size_t)n * d, 1u); fill_kernel<<<8, 256>>>(q, d, 7u); CK(hipDeviceSynchronize());
-  std::vector<Cfg> cfgs = { K(1,16,true,false),
-    O(1,4,true,false), O(1,8,true,false), O(1,16,true,false), O(1,16,false,false),
-    O(1,4,true,true), O(1,8,true,true), O(1,16,true,true),
-    O(2,4,true,true), O(2,8,true,true), O(2,16,true,true), O(2,16,true,false), O(2,8,true,false),
-    O(4,4,true,true), O(4,8,true,true), O(4,16,true,true), O(4,4,true,false), O(4,8,true,false) };
+  std::vector<Cfg> cfgs = {
+    O(1,16,true,false), Cfg{"one1r16w-xcdmap", 1, 16, true, false, gemv_f32_oneshot_kernel<6, 1, 16, true, false, true>},
+    O(2,16,true,false), Cfg{"one2r16w-xcdmap", 2, 16, true, false, gemv_f32_oneshot_kernel<6, 2, 16, true, false, true>},
+    O(1,8,true,false), Cfg{"one1r8w-xcdmap", 1, 8, true, false, gemv_f32_oneshot_kernel<6, 1, 8, true, false, true>},
+    O(4,16,true,false), O(1,16,true,false) };
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const int bpcs[] = {9999};
   for (auto& c : cfgs) {
