@@ -76,6 +76,8 @@ const char* svs_version(void);
 const char* svs_last_error(void);
 /* Number of visible HIP devices (0 when none; never fails). */
 int32_t svs_device_count(void);
+/* Free / total HBM of a device in bytes (capacity planning, leak tests). */
+int32_t svs_device_memory(int32_t device, int64_t* free_bytes, int64_t* total_bytes);
 
 /* ---- index lifetime: replaces the cached (embeddings_matrix, emb_id_lookup)
  *      pair of _EmbeddingsMatrix, src/svs/kb.py:856-893 --------------------- */

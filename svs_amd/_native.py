@@ -52,6 +52,7 @@ SIGNATURES = {
     "svs_version": (C.c_char_p, []),
     "svs_last_error": (C.c_char_p, []),
     "svs_device_count": (C.c_int32, []),
+    "svs_device_memory": (C.c_int32, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "svs_index_create": (C.c_int32, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.POINTER(_P)]),
     "svs_index_create_from_device": (C.c_int32, [_P, C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.POINTER(_P)]),
     "svs_index_append": (C.c_int32, [_P, _P, C.c_int64]),
@@ -77,6 +78,29 @@ def lib_path() -> str:
     return _LIB_PATH
 
 
+def _share_torch_hip_runtime() -> None:
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own
+    libamdhip64 (SONAME libamdhip64.so.7, looked up as plain "libamdhip64.so"); if
+    this library pulled in the system copy first, a later ``import torch`` would
+    load a SECOND runtime and fail with "No HIP GPUs are available", and stream
+    handles could not be shared.  So when such a wheel is installed and torch is
+    not loaded yet, its runtime is loaded first and libsvs_amd binds to it.
+    Opt out with SVS_AMD_SYSTEM_HIP=1."""
+    import sys
+    if os.environ.get("SVS_AMD_SYSTEM_HIP") or "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:  # noqa: BLE001 -- fall back to the system runtime
+        pass
+
+
 def load() -> C.CDLL:
     """Loads the HIP library (once).  Raises RuntimeError when it is missing --
     there is deliberately nothing to fall back to."""
@@ -88,6 +112,7 @@ def load() -> C.CDLL:
             f"svs_amd: HIP library not built ({_LIB_PATH}); run `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C svs_amd/csrc`. There is no CPU fallback."
         )
+    _share_torch_hip_runtime()
     lib = C.CDLL(_LIB_PATH)  # CDLL releases the GIL around every call
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
@@ -118,3 +143,10 @@ def check(rc: int) -> None:
 
 def device_count() -> int:
     return int(load().svs_device_count())
+
+
+def device_memory(device: int = 0):
+    """(free, total) HBM bytes."""
+    f, t = C.c_int64(0), C.c_int64(0)
+    check(load().svs_device_memory(int(device), C.byref(f), C.byref(t)))
+    return f.value, t.value

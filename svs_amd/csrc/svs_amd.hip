@@ -811,6 +811,16 @@ int32_t svs_device_count(void) {
   return n;
 }
 
+int32_t svs_device_memory(int32_t device, int64_t* free_bytes, int64_t* total_bytes) {
+  HIP_TRY(hipSetDevice(device));
+  size_t f = 0, t = 0;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemGetInfo(&f, &t));
+  if (free_bytes) *free_bytes = (int64_t)f;
+  if (total_bytes) *total_bytes = (int64_t)t;
+  return SVS_OK;
+}
+
 int32_t svs_index_create(const float* host_rows, int64_t n, int32_t d, int32_t store_dtype,
                          int32_t device, int64_t row_offset, svs_index** out) {
   svs_index* idx = nullptr;

@@ -246,8 +246,7 @@ def test_select_window_fallbacks(gpu):
 def test_no_hbm_leak_over_index_lifetimes(gpu):
     """create / search / release in a loop must give the HBM back (contexts, scratch,
     staging buffers and the corpus are all owned by the handle)."""
-    import torch
-    from svs_amd import DeviceIndex
+    from svs_amd import DeviceIndex, _native
     m, qs = corpus_and_query("gaussian", 1, 40000, 512, 20)
     free0 = None
     for it in range(12):
@@ -256,8 +255,7 @@ def test_no_hbm_leak_over_index_lifetimes(gpu):
         idx.search_batch(qs, 10)
         idx.top_pairs(5) if it == 0 else None
         idx.release()
-        torch.cuda.synchronize()
-        free, _ = torch.cuda.mem_get_info()
+        free, _ = _native.device_memory(0)
         if it == 2:
             free0 = free
     assert free0 - free < 64 << 20, f"HBM shrank by {(free0 - free) >> 20} MiB over 9 index lifetimes"
