@@ -10,5 +10,6 @@ from ._native import device_count, lib_path  # noqa: F401
 from .index import DeviceIndex  # noqa: F401
 from .kb import KB, AsyncKB  # noqa: F401
 from .matrix import DeviceEmbeddingsMatrix, attach  # noqa: F401
+from .multi import MultiDeviceIndex  # noqa: F401
 
 __version__ = "0.1.0"

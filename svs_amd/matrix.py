@@ -324,10 +324,16 @@ class DeviceMatrixView:
         return func(*[np.asarray(a) if isinstance(a, DeviceMatrixView) else a for a in args], **kwargs)
 
 
-def attach(kb, device: int = 0, keep_host_matrix: bool = True, index_factory: Callable[..., Any] = DeviceIndex):
+def attach(kb, device: int = 0, keep_host_matrix: bool = True, index_factory: Callable[..., Any] = DeviceIndex,
+           devices: Optional[List[int]] = None):
     """Swap a reference ``svs.KB`` / ``svs.AsyncKB`` instance's matrix cache for
     the device-backed one.  No reference source line changes; ``retrieve()``
-    keeps its exact surface."""
+    keeps its exact surface.  ``devices=[0, 1, ...]`` row-shards the corpus over
+    several GPUs of this process (``svs_amd.multi.MultiDeviceIndex``)."""
+    if devices is not None and len(devices) > 1:
+        import functools
+        from .multi import MultiDeviceIndex
+        index_factory = functools.partial(MultiDeviceIndex, devices=list(devices))
     old = kb.embeddings_matrix
     new = DeviceEmbeddingsMatrix(device=device, keep_host_matrix=keep_host_matrix,
                                  index_factory=index_factory, view=True)

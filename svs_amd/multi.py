@@ -1,0 +1,152 @@
+"""
+MultiDeviceIndex: one process, several MI355X, the corpus row-sharded across them
+(the in-process form of the C-ABI sketch's ``devices, ndev``).
+
+For a single Python process that owns all GPUs of a node -- the way ``svs.KB`` is
+normally used -- this needs no launcher and no RCCL: shard g holds the contiguous
+row block ``shard_bounds(N, G, g)`` on device ``devices[g]`` with
+``row_offset = lo``; a search runs on all shards concurrently (ctypes releases the
+GIL inside the C ABI, so one thread per shard is real parallelism), every shard
+returns its local top-k with GLOBAL rows (1.2 KB each, written zero-copy into pinned
+host memory), and the host merges them under the same total order
+(score desc, row desc).  The merged result is identical to a single-device index:
+a row's score does not depend on where the row lives.
+
+(The one-process-per-GPU form over torch.distributed/RCCL is ``svs_amd.sharded``.)
+"""
+from __future__ import annotations
+
+import threading
+from concurrent.futures import ThreadPoolExecutor
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .index import DeviceIndex
+from .sharded import merge_topk, shard_bounds
+
+
+class MultiDeviceIndex:
+    """Has the surface of ``DeviceIndex`` that the KB layer uses (search,
+    search_batch, scores, append, mask_rows, share, release, shape)."""
+
+    def __init__(self, matrix: Optional[np.ndarray], devices: Sequence[int] = (0,), device: Optional[int] = None,
+                 dtype: str = "f32", *, _shards: Optional[List[DeviceIndex]] = None, _bounds=None):
+        if _shards is not None:
+            self._shards, self._bounds = _shards, list(_bounds)
+        else:
+            m = np.ascontiguousarray(matrix, dtype=np.float32)
+            if m.ndim != 2:
+                raise ValueError(f"embeddings matrix must be 2-D, got shape {m.shape}")
+            devices = list(devices)
+            g = len(devices)
+            self._bounds = [shard_bounds(m.shape[0], g, r) for r in range(g)]
+            self._shards = []
+            try:
+                # uploads run concurrently: each shard has its own pinned staging and stream
+                with ThreadPoolExecutor(max_workers=g) as ex:
+                    futs = [ex.submit(DeviceIndex, m[lo:hi], devices[r], lo, dtype) for r, (lo, hi) in enumerate(self._bounds)]
+                    for f in futs:
+                        self._shards.append(f.result())
+            except BaseException:
+                for s in self._shards:
+                    s.release()
+                raise
+        self._pool = ThreadPoolExecutor(max_workers=max(1, len(self._shards)))
+        self._mu = threading.Lock()
+        self.d = self._shards[0].d
+        self.dtype = self._shards[0].dtype
+        self.row_offset = 0
+
+    # -- geometry -----------------------------------------------------------
+    @property
+    def n(self) -> int:
+        return sum(s.n for s in self._shards)
+
+    @property
+    def shape(self) -> Tuple[int, int]:
+        return (self.n, self.d)
+
+    def __len__(self) -> int:
+        return self.n
+
+    @property
+    def n_masked(self) -> int:
+        return sum(s.n_masked for s in self._shards)
+
+    @property
+    def devices(self) -> List[int]:
+        return [s.device for s in self._shards]
+
+    # -- lifetime -------------------------------------------------------------
+    def share(self) -> "MultiDeviceIndex":
+        return MultiDeviceIndex(None, _shards=[s.share() for s in self._shards], _bounds=self._bounds)
+
+    def release(self) -> None:
+        for s in self._shards:
+            s.release()
+        self._pool.shutdown(wait=False)
+
+    close = release
+
+    # -- search ---------------------------------------------------------------
+    def search_batch(self, queries: np.ndarray, n: int) -> Tuple[np.ndarray, np.ndarray]:
+        assert isinstance(n, int)
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim != 2:
+            raise ValueError(f"queries must be 2-D, got shape {q.shape}")
+        live = [s for s in self._shards if s.n > 0]
+        if not live or q.shape[1] != self.d:
+            # same error as numpy / a single index
+            return self._shards[0].search_batch(q, n)
+        parts = list(self._pool.map(lambda s: s.search_batch(q, n), live))
+        k = max(n, 0)
+        count = min(k, self.n - self.n_masked)
+        out_s = np.empty((q.shape[0], count), dtype=np.float32)
+        out_r = np.empty((q.shape[0], count), dtype=np.int64)
+        for i in range(q.shape[0]):
+            s = np.concatenate([p[0][i] for p in parts])
+            r = np.concatenate([p[1][i] for p in parts])
+            out_s[i], out_r[i] = merge_topk(s, r, count)
+        return out_s, out_r
+
+    def search(self, query_vec: np.ndarray, n: int) -> List[Tuple[float, int]]:
+        assert isinstance(n, int)
+        q = np.asarray(query_vec, dtype=np.float32)
+        if q.ndim != 1:
+            raise ValueError(f"query must be 1-D, got shape {q.shape}")
+        s, r = self.search_batch(q[None, :], n)
+        return [(float(a), int(b)) for a, b in zip(s[0], r[0])]
+
+    def scores(self, query_vec: np.ndarray) -> np.ndarray:
+        parts = list(self._pool.map(lambda s: s.scores(query_vec), [s for s in self._shards if s.n > 0]))
+        return np.concatenate(parts) if parts else np.empty(0, dtype=np.float32)
+
+    # -- incremental update -----------------------------------------------------
+    def append(self, matrix: np.ndarray) -> None:
+        """New rows go behind the LAST shard (global row = previous N + i), so existing
+        global row numbers -- and the caller's emb_id_lookup -- stay valid."""
+        with self._mu:
+            self._shards[-1].append(matrix)
+            lo, _ = self._bounds[-1]
+            self._bounds[-1] = (lo, lo + self._shards[-1].n)
+
+    def mask_rows(self, rows) -> None:
+        r = np.asarray(rows, dtype=np.int64)
+        with self._mu:
+            for s, (lo, hi) in zip(self._shards, self._bounds):
+                mine = r[(r >= lo) & (r < hi)]
+                if len(mine):
+                    s.mask_rows(mine)
+            if np.any((r < 0) | (r >= self.n)):
+                raise ValueError("row out of range")
+
+    def top_pairs(self, n: int):
+        raise NotImplementedError("pairwise scores need the whole corpus on one device; build a DeviceIndex for it")
+
+    def stored_rows(self, row0: int = 0, nrows: Optional[int] = None) -> np.ndarray:
+        full = np.concatenate([s.stored_rows() for s in self._shards if s.n > 0])
+        return full[row0:(None if nrows is None else row0 + nrows)]
+
+    def stored_query(self, query_vec: np.ndarray) -> np.ndarray:
+        return self._shards[0].stored_query(query_vec)

@@ -188,3 +188,38 @@ def test_two_shards_on_one_gpu_equal_one_index(gpu):
         for s in shards:
             s.release()
     whole.release()
+
+
+@pytest.mark.gpu
+def test_multi_device_index_in_one_process(gpu):
+    """MultiDeviceIndex (threads, no RCCL): shards on the same card here; results must be
+    identical to one index, through searches, appends and tombstones, and under the KB."""
+    import functools
+    import svs_amd
+    from svs_amd import DeviceIndex, MultiDeviceIndex
+    n, d, k = 50003, 768, 100
+    m, qs = corpus_and_query("gaussian", 43, n, d, 5)
+    whole = DeviceIndex(m[:40000])
+    multi = MultiDeviceIndex(m[:40000], devices=[0, 0, 0])
+    assert multi.shape == (40000, d) and multi.devices == [0, 0, 0]
+    for q in qs:
+        assert multi.search(q, k) == whole.search(q, k)
+    ws, wr = whole.search_batch(qs, 33)
+    ms, mr = multi.search_batch(qs, 33)
+    assert np.array_equal(ws, ms) and np.array_equal(wr, mr)
+    whole.append(m[40000:]); multi.append(m[40000:])
+    dead = [5, 13334, 26667, 39999, 40000, 50002] + [r for _, r in whole.search(qs[1], 10)]
+    whole.mask_rows(dead); multi.mask_rows(dead)
+    assert multi.n_masked == whole.n_masked == len(set(dead))
+    for q in qs:
+        assert multi.search(q, k) == whole.search(q, k)
+    assert len(multi.search(qs[0], 10 ** 6)) == n - len(set(dead))
+    with pytest.raises(ValueError):
+        multi.search(qs[0][:5], 3)
+    held = multi.share()
+    multi.release()
+    assert held.search(qs[2], 7) == whole.search(qs[2], 7)      # a shared owner keeps every shard alive
+    held.release(); whole.release()
+    tiny = MultiDeviceIndex(m[:2], devices=[0, 0, 0, 0])          # fewer rows than shards
+    assert [r for _, r in tiny.search(qs[0], 5)] == [r for _, r in oracle.total_order_top_k(oracle.cpu_scores(m[:2], qs[0]), 5)]
+    tiny.release()
