@@ -168,8 +168,9 @@ int32_t svs_index_debug_dequant(svs_index* idx, int64_t row0, int64_t nrows, flo
 int32_t svs_index_debug_query(svs_index* idx, const float* query, int32_t d, float* out);
 
 /* ---- measurement --------------------------------------------------------- */
-/* enable != 0: record HIP events around the score and select stages of every
- * subsequent search on this handle and accumulate them. */
+/* enable = N > 0: record HIP events around the score and select stages of every N-th
+ * subsequent search on this handle and accumulate them (N = 1: every search; the three
+ * event records cost ~10 us of stream time per timed search).  0: off. */
 int32_t svs_index_set_timing(svs_index* idx, int32_t enable);
 /* Waits for outstanding timed searches, returns the sums, and resets them. */
 int32_t svs_index_get_timing(svs_index* idx, svs_timing_t* out);

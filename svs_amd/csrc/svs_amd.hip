@@ -102,7 +102,8 @@ struct svs_index {
   int n_ctx = 0;
   static constexpr int kMaxCtx = 8;
 
-  std::atomic<int> timing{0};
+  std::atomic<int> timing{0};          // 0 off, N: time every N-th search
+  std::atomic<uint32_t> timing_seq{0};
   std::atomic<int> variant{0};
   std::vector<EvTriple> evs;  // guarded by mu
 };
@@ -629,7 +630,8 @@ int enqueue_search(svs_index* idx, Ctx* c, const float* q_dev, int nq, int k, in
   }
 
   EvTriple ev{};
-  const bool timed = idx->timing.load() != 0;
+  const int tevery = idx->timing.load();
+  const bool timed = tevery > 0 && (idx->timing_seq.fetch_add(1) % (uint32_t)tevery) == 0;
   if (timed) {
     HIP_TRY(hipEventCreate(&ev.e0));
     HIP_TRY(hipEventCreate(&ev.e1));
@@ -1198,7 +1200,8 @@ int32_t svs_index_debug_query(svs_index* idx, const float* query, int32_t d, flo
 
 int32_t svs_index_set_timing(svs_index* idx, int32_t enable) {
   if (!idx) return fail(SVS_ERR_INVALID, "null index");
-  idx->timing.store(enable ? 1 : 0);
+  idx->timing.store(enable > 0 ? enable : 0);
+  idx->timing_seq.store(0);
   return SVS_OK;
 }
 

@@ -235,8 +235,9 @@ class DeviceIndex:
         return out
 
     # -- measurement ------------------------------------------------------
-    def set_timing(self, enable: bool) -> None:
-        _native.check(self._lib.svs_index_set_timing(self._handle(), 1 if enable else 0))
+    def set_timing(self, enable) -> None:
+        """True / 1: time every search; N: every N-th; False / 0: off."""
+        _native.check(self._lib.svs_index_set_timing(self._handle(), int(enable)))
 
     def get_timing(self) -> Tuple[float, float, int]:
         t = _native.Timing()
