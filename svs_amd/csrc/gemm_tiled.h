@@ -175,25 +175,30 @@ __global__ __launch_bounds__(TG_WAVES * 64) void gemm_tiled_kernel(
     const u32x4* A = ldsA(cur);
     const u32x4* B = ldsB(cur);
     if constexpr (EB == 2) {
+      // both 32-wide k-halves' fragments are requested before the first MFMA: the second
+      // half's LDS latency hides under the first half's MFMAs (lane holds halves 8g..8g+7
+      // of a half = one 16-byte chunk)
+      h8 fa[2][MT], fb[2][NT];
 #pragma unroll
-      for (int kh = 0; kh < 2; ++kh) {   // two 32-wide k-halves; lane holds halves 8g..8g+7 = one 16-B chunk
-        h8 fa[MT], fb[NT];
+      for (int kh = 0; kh < 2; ++kh) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
           const int r = wm * TM + i * 16 + r16;
-          fa[i] = __builtin_bit_cast(h8, A[r * 8 + ((4 * kh + g) ^ tg_swz(r))]);
+          fa[kh][i] = __builtin_bit_cast(h8, A[r * 8 + ((4 * kh + g) ^ tg_swz(r))]);
         }
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           const int r = wn * TN + j * 16 + r16;
-          fb[j] = __builtin_bit_cast(h8, B[r * 8 + ((4 * kh + g) ^ tg_swz(r))]);
+          fb[kh][j] = __builtin_bit_cast(h8, B[r * 8 + ((4 * kh + g) ^ tg_swz(r))]);
         }
+      }
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-      }
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[kh][i], fb[kh][j], acc[i][j], 0, 0, 0);
     } else if constexpr (EB == 4) {
       // exact f32: v_mfma_f32_16x16x4_f32 (bit-for-bit an fmaf chain).  A 128-byte stage is 32
       // floats per row; lane (r16, g) takes chunk 4t + g of sub-step t and its four components
