@@ -30,6 +30,7 @@
 #include <stdint.h>
 
 #include "gemv_f32.h"
+#include "keys.h"
 
 namespace svs {
 
@@ -38,14 +39,34 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int GQ = 16;        // queries per pass
 constexpr int GEMM_WAVES = 8;
 constexpr int GEMM_PF = 8;    // k-steps prefetched per tile half
+constexpr int GEMM_LCAND = 1024;  // fused epilogue: candidates a workgroup parks in LDS before its one flush
+constexpr int GEMM_FUSE_LDS = 8 + GEMM_LCAND * 12;   // counter + keys (u64) + query ids (u32), after the query image
 
 // Q16: [16][ld] f32 (rows >= nq zero).  scores: [16][sstride].
-template <bool NT, int TILES = 2, int PF = GEMM_PF>
+//
+// FUSE: no score matrix.  Writing 16 x n scores is only 1 % of the bytes but the writes,
+// mixed into a saturating read stream, cost 10-12 % of the kernel (measured: ~1.6 us
+// per MB whatever their layout); instead a score is offered to the query's candidate
+// list when it reaches thr[q], a proven lower bound of the k-th best (the exact k-th
+// best of a prefix of the rows, gemm_tiled.h has the full argument).  Header word 0 =
+// candidate count, as select.h expects; row numbers are LOCAL (select_final adds
+// row_offset).  A returning global atomic in the row loop would make the wave wait on
+// vmcnt(0) -- i.e. drain its prefetched loads -- once per tile (measured: 1.14 ms, slower
+// than storing the scores); so candidates are parked in LDS (ds atomics count on lgkmcnt)
+// and the workgroup claims its global slots once, at the end.  If the LDS list is
+// full (adversarial row order) the lane goes to the global list directly.
+template <bool NT, int TILES = 2, int PF = GEMM_PF, bool FUSE = false>
 __global__ __launch_bounds__(GEMM_WAVES * 64) void gemm_f32_q16_kernel(
     const float* __restrict__ M, const float* __restrict__ Q16, float* __restrict__ scores,
-    int64_t n, int ld, int64_t sstride, int nq, int rows_per_block) {
-  extern __shared__ v4f qlds[];  // [ld/16][64]
+    int64_t n, int ld, int64_t sstride, int nq, int rows_per_block,
+    uint32_t* __restrict__ fstate = nullptr, int fstate_stride = 0, uint64_t* __restrict__ fcand = nullptr,
+    uint32_t fcap = 0, const float* __restrict__ fthr = nullptr, int fthr_stride = 0) {
+  extern __shared__ v4f qlds[];  // [ld/16][64], then (FUSE) the parked candidates
   const int ksteps = ld >> 4;
+  uint32_t* lcount = (uint32_t*)(qlds + (size_t)ksteps * 64);
+  uint64_t* lkey = (uint64_t*)(lcount + 2);
+  uint32_t* lqid = (uint32_t*)(lkey + GEMM_LCAND);
+  if (FUSE && threadIdx.x == 0) lcount[0] = 0;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // ---- stage the queries in MFMA-B order
@@ -59,21 +80,31 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void gemm_f32_q16_kernel(
   const int64_t blk1 = blk0 + rows_per_block < n ? blk0 + rows_per_block : n;
   const int r16 = lane & 15, g = lane >> 4;
   constexpr int TROWS = 16 * TILES;
-  for (int64_t row0 = blk0 + wave * TROWS; row0 < blk1; row0 += GEMM_WAVES * TROWS) {
-    const v4f* p[TILES];
-    f32x4 acc[TILES];
+  // The (tile, chunk) walk is one continuous stream: the first chunk of the NEXT tile is
+  // requested before the last chunk of this one is multiplied, so a wave never sits with
+  // nothing in flight, and the score stores (which share vmcnt with the loads on gfx9
+  // and complete in order with them) are never waited for.
+  auto tile_ptrs = [&](int64_t row0, const v4f* (&p)[TILES]) {
 #pragma unroll
     for (int t = 0; t < TILES; ++t) {
       int64_t r = row0 + 16 * t + r16;
       r = r < n ? r : n - 1;  // clamp: never read past the matrix
       p[t] = (const v4f*)(M + r * ld + 4 * g);
-      acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    v4f a[TILES][PF];
+  };
+  int64_t row0 = blk0 + wave * TROWS;
+  if (!FUSE && row0 >= blk1) return;   // (fused: every wave reaches the flush barrier)
+  const v4f* p[TILES];
+  tile_ptrs(row0, p);
+  v4f a[TILES][PF];
 #pragma unroll
-    for (int t = 0; t < TILES; ++t)
+  for (int t = 0; t < TILES; ++t)
 #pragma unroll
-      for (int j = 0; j < PF; ++j) a[t][j] = ldg4<NT>(p[t] + 4 * j);   // step j: columns 16 j + 4 g .. +4
+    for (int j = 0; j < PF; ++j) a[t][j] = ldg4<NT>(p[t] + 4 * j);   // step j: columns 16 j + 4 g .. +4
+  for (; row0 < blk1; row0 += GEMM_WAVES * TROWS) {
+    f32x4 acc[TILES];
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     auto mul_chunk = [&](int s0) {
 #pragma unroll
       for (int j = 0; j < PF; ++j) {
@@ -88,9 +119,8 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void gemm_f32_q16_kernel(
         for (int t = 0; t < TILES; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][j].w, qf.w, acc[t], 0, 0, 0);
       }
     };
-    // Steady state has NO conditional around the prefetch: a branch there makes hipcc wait
-    // for the just-issued loads at the join (the same trap as in gemv_f32.h); the last
-    // chunk is peeled instead.
+    // No conditional around a prefetch anywhere: a branch there makes hipcc wait for the
+    // just-issued loads at the join (the same trap as in gemv_f32.h).
     int s0 = 0;
     for (; s0 + PF < ksteps; s0 += PF) {
       v4f nx[TILES][PF];
@@ -104,9 +134,51 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void gemm_f32_q16_kernel(
 #pragma unroll
         for (int j = 0; j < PF; ++j) a[t][j] = nx[t][j];
     }
-    mul_chunk(s0);
+    {
+      // last chunk of this tile: the next tile's first chunk goes out first (past the
+      // block's end the rows clamp to valid memory and the data is never used)
+      const v4f* pn[TILES];
+      tile_ptrs(row0 + GEMM_WAVES * TROWS, pn);
+      v4f nx[TILES][PF];
+#pragma unroll
+      for (int t = 0; t < TILES; ++t)
+#pragma unroll
+        for (int j = 0; j < PF; ++j) nx[t][j] = ldg4<NT>(pn[t] + 4 * j);
+      mul_chunk(s0);
+#pragma unroll
+      for (int t = 0; t < TILES; ++t) {
+        p[t] = pn[t];
+#pragma unroll
+        for (int j = 0; j < PF; ++j) a[t][j] = nx[t][j];
+      }
+    }
     // D layout: column (query) = lane & 15, rows 4 g + r of the 16-row tile
-    if (r16 < nq) {
+    if constexpr (FUSE) {
+      if (r16 < nq) {
+        uint32_t* hdr = fstate + (int64_t)r16 * fstate_stride;
+        uint64_t* cq = fcand + (int64_t)r16 * fcap;
+        const float thr = fthr[(int64_t)r16 * fthr_stride];
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) {
+          const int64_t ob = row0 + 16 * t + 4 * g;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = acc[t][r];
+            if (v >= thr && ob + r < blk1) {
+              const uint64_t key = ((uint64_t)score_key(v) << 32) | (uint32_t)(ob + r);
+              const uint32_t ls = atomicAdd(lcount, 1u);
+              if (ls < (uint32_t)GEMM_LCAND) {
+                lkey[ls] = key;
+                lqid[ls] = (uint32_t)r16;
+              } else {
+                const uint32_t slot = atomicAdd(hdr, 1u);
+                if (slot < fcap) cq[slot] = key;
+              }
+            }
+          }
+        }
+      }
+    } else if (r16 < nq) {
       float* o = scores + (int64_t)r16 * sstride;
 #pragma unroll
       for (int t = 0; t < TILES; ++t) {
@@ -116,6 +188,183 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void gemm_f32_q16_kernel(
           for (int r = 0; r < 4; ++r)
             if (ob + r < blk1) o[ob + r] = acc[t][r];
       }
+    }
+  }
+  if constexpr (FUSE) {
+    __syncthreads();
+    const uint32_t parked = lcount[0] < (uint32_t)GEMM_LCAND ? lcount[0] : (uint32_t)GEMM_LCAND;
+    for (uint32_t i = threadIdx.x; i < parked; i += GEMM_WAVES * 64) {
+      const uint32_t q = lqid[i];
+      const uint32_t slot = atomicAdd(fstate + (int64_t)q * fstate_stride, 1u);
+      if (slot < fcap) fcand[(int64_t)q * fcap + slot] = lkey[i];
+    }
+  }
+}
+
+// ---- the same product on v_mfma_f32_4x4x1_16b_f32: full-line loads ---------------
+// The 16x16x4 kernel above gives each lane one float4 of ITS row per instruction: 64
+// contiguous bytes per row, half a cache line, which caps the stream at ~6.1 TB/s (and
+// rules out nontemporal loads, see above).  The 4x4x1 instruction runs 16 independent
+// 4x4 outer products, one per group of 4 lanes ("block" b = lane >> 2): lane (b, i)
+// supplies A = row i's element and B = query i's element of block b's column, and
+// block b accumulates the partial product of ITS columns.  So lane (b, i) loads float4
+// #b of a 64-column step of row i: an instruction covers 4 rows x 256 contiguous bytes,
+// whole lines, nontemporal -- 6.9 TB/s for the bare pattern (tools/pattern_bw.hip).
+// Same f32 MFMA rate (32 MAC/clk/SIMD for every f32 shape), 4 queries per instruction,
+// so 16 queries are 4 query groups m; a wave iteration is RG = 4 row groups (16 rows).
+// After the last step the 16 per-block partial sums of every (row, query) are added
+// across lanes (2 DPP row rotations + 2 bpermutes per value); the order depends only on
+// d.  Query image in LDS: [m][step][lane] float4 = Q[4m + (lane&3)][64 step + 4 (lane>>2) ..].
+constexpr int G4_RG = 4;
+constexpr int G4_PF = 2;     // 64-column steps per register buffer (ld % 128 == 0)
+
+template <bool FUSE, int RG = G4_RG, int PF = G4_PF>
+__global__ __launch_bounds__(GEMM_WAVES * 64) void gemm_f32_q16r_kernel(
+    const float* __restrict__ M, const float* __restrict__ Q16, float* __restrict__ scores,
+    int64_t n, int ld, int64_t sstride, int nq, int rows_per_block,
+    uint32_t* __restrict__ fstate = nullptr, int fstate_stride = 0, uint64_t* __restrict__ fcand = nullptr,
+    uint32_t fcap = 0, const float* __restrict__ fthr = nullptr, int fthr_stride = 0) {
+  extern __shared__ v4f qlds[];  // [4][ld/64][64], then (FUSE) the parked candidates
+  const int ksteps = ld >> 6;
+  uint32_t* lcount = (uint32_t*)(qlds + (size_t)ksteps * 256);
+  uint64_t* lkey = (uint64_t*)(lcount + 2);
+  uint32_t* lqid = (uint32_t*)(lkey + GEMM_LCAND);
+  if (FUSE && threadIdx.x == 0) lcount[0] = 0;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int e = threadIdx.x; e < ksteps * 256; e += GEMM_WAVES * 64) {
+    const int m = e / (ksteps * 64), rem = e - m * ksteps * 64;
+    const int s = rem >> 6, l = rem & 63;
+    qlds[e] = *(const v4f*)(Q16 + (int64_t)(4 * m + (l & 3)) * ld + 64 * s + 4 * (l >> 2));
+  }
+  __syncthreads();
+
+  const int64_t blk0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t blk1 = blk0 + rows_per_block < n ? blk0 + rows_per_block : n;
+  const int i4 = lane & 3, b = lane >> 2;
+  constexpr int TROWS = 4 * RG;
+  auto group_ptrs = [&](int64_t row0, const v4f* (&p)[RG]) {
+#pragma unroll
+    for (int t = 0; t < RG; ++t) {
+      int64_t r = row0 + 4 * t + i4;
+      r = r < n ? r : n - 1;  // clamp: never read past the matrix
+      p[t] = (const v4f*)(M + r * ld + 4 * b);
+    }
+  };
+  int64_t row0 = blk0 + wave * TROWS;
+  if (!FUSE && row0 >= blk1) return;   // (fused: every wave reaches the flush barrier)
+  const v4f* p[RG];
+  group_ptrs(row0, p);
+  v4f a[RG][PF];
+#pragma unroll
+  for (int t = 0; t < RG; ++t)
+#pragma unroll
+    for (int j = 0; j < PF; ++j) a[t][j] = ldg4<true>(p[t] + 16 * j);
+  for (; row0 < blk1; row0 += GEMM_WAVES * TROWS) {
+    f32x4 acc[RG][4];
+#pragma unroll
+    for (int t = 0; t < RG; ++t)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) acc[t][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto mul_chunk = [&](int s0) {
+#pragma unroll
+      for (int j = 0; j < PF; ++j) {
+        v4f qf[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) qf[m] = qlds[(m * ksteps + s0 + j) * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int t = 0; t < RG; ++t)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+              acc[t][m] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[t][j][e], qf[m][e], acc[t][m], 0, 0, 0);
+      }
+    };
+    int s0 = 0;
+    for (; s0 + PF < ksteps; s0 += PF) {
+      v4f nx[RG][PF];
+#pragma unroll
+      for (int t = 0; t < RG; ++t)
+#pragma unroll
+        for (int j = 0; j < PF; ++j) nx[t][j] = ldg4<true>(p[t] + 16 * (s0 + PF + j));
+      mul_chunk(s0);
+#pragma unroll
+      for (int t = 0; t < RG; ++t)
+#pragma unroll
+        for (int j = 0; j < PF; ++j) a[t][j] = nx[t][j];
+    }
+    {
+      const v4f* pn[RG];
+      group_ptrs(row0 + GEMM_WAVES * TROWS, pn);
+      v4f nx[RG][PF];
+#pragma unroll
+      for (int t = 0; t < RG; ++t)
+#pragma unroll
+        for (int j = 0; j < PF; ++j) nx[t][j] = ldg4<true>(pn[t] + 16 * j);
+      mul_chunk(s0);
+#pragma unroll
+      for (int t = 0; t < RG; ++t) {
+        p[t] = pn[t];
+#pragma unroll
+        for (int j = 0; j < PF; ++j) a[t][j] = nx[t][j];
+      }
+    }
+    // acc[t][m][r] in lane (b, j): block b's share of (row 4t + r, query 4m + j).  Sum over b;
+    // lane (b, j) then keeps (t, m) = (b >> 2, b & 3): rows 4t .. 4t+3 of query 4m + j.
+    f32x4 out = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < RG; ++t)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        f32x4 v = acc[t][m];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float x = v[r];
+          x += dpp_mov<0x124>(x);   // row_ror:4
+          x += dpp_mov<0x128>(x);   // row_ror:8
+          x += __shfl_xor(x, 16, 64);
+          x += __shfl_xor(x, 32, 64);
+          v[r] = x;
+        }
+        out = (b == 4 * t + m) ? v : out;
+      }
+    const int query = b < 4 * RG ? 4 * (b & 3) + i4 : GQ;   // lanes past the (t, m) combinations hold nothing
+    const int64_t ob = row0 + 4 * (b >> 2);
+    if constexpr (FUSE) {
+      if (query < nq) {
+        const float thr = fthr[(int64_t)query * fthr_stride];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = out[r];
+          if (v >= thr && ob + r < blk1) {
+            const uint64_t key = ((uint64_t)score_key(v) << 32) | (uint32_t)(ob + r);
+            const uint32_t ls = atomicAdd(lcount, 1u);
+            if (ls < (uint32_t)GEMM_LCAND) {
+              lkey[ls] = key;
+              lqid[ls] = (uint32_t)query;
+            } else {
+              const uint32_t slot = atomicAdd(fstate + (int64_t)query * fstate_stride, 1u);
+              if (slot < fcap) fcand[(int64_t)query * fcap + slot] = key;
+            }
+          }
+        }
+      }
+    } else if (query < nq) {
+      float* o = scores + (int64_t)query * sstride;
+      if (ob + 3 < blk1) *(f32x4*)(o + ob) = out;
+      else
+        for (int r = 0; r < 4; ++r)
+          if (ob + r < blk1) o[ob + r] = out[r];
+    }
+  }
+  if constexpr (FUSE) {
+    __syncthreads();
+    const uint32_t parked = lcount[0] < (uint32_t)GEMM_LCAND ? lcount[0] : (uint32_t)GEMM_LCAND;
+    for (uint32_t i = threadIdx.x; i < parked; i += GEMM_WAVES * 64) {
+      const uint32_t q = lqid[i];
+      const uint32_t slot = atomicAdd(fstate + (int64_t)q * fstate_stride, 1u);
+      if (slot < fcap) fcand[(int64_t)q * fcap + slot] = lkey[i];
     }
   }
 }

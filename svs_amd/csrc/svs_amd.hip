@@ -61,6 +61,7 @@ struct Ctx {
   uint8_t* q8 = nullptr;        size_t q8_cap = 0;       // e4m3 queries [rows][ld], zero padded
   float* q8f = nullptr;         size_t q8f_cap = 0;      // the same values as f32 (single-query kernel)
   float* q8s = nullptr;         size_t q8s_cap = 0;      // query scales
+  const float* q_f32 = nullptr;                          // staged f32 queries (q16 or the caller's buffer)
   float* pref_s = nullptr;      size_t pref_s_cap = 0;   // fused GEMM: top-k of the prefix rows (thresholds)
   int64_t* pref_r = nullptr;    size_t pref_r_cap = 0;
   float* scores = nullptr;      size_t scores_cap = 0;   // floats
@@ -419,42 +420,65 @@ bool batch_kernel_ok(const svs_index* idx) {
   return idx->dtype == SVS_DTYPE_F32 && idx->ld % 128 == 0 && idx->ld <= 2304 && idx->variant.load() != 7;
 }
 
-int launch_scores_q16(const svs_index* idx, Ctx* c, const float* q_dev, int nq_g, float* scores,
-                      int64_t sstride, hipStream_t st) {
-  const int ld = idx->ld;
-  const float* q16 = q_dev;
-  if (nq_g < GQ || ld != idx->d || (((uintptr_t)q_dev) & 15)) {  // zero-pad to 16 queries x ld columns
-    int rc = grow_dev(&c->q16, &c->q16_cap, (size_t)GQ * ld);
-    if (rc != SVS_OK) return rc;
-    HIP_TRY(hipMemsetAsync(c->q16, 0, (size_t)GQ * ld * sizeof(float), st));
-    HIP_TRY(hipMemcpy2DAsync(c->q16, (size_t)ld * sizeof(float), q_dev, (size_t)idx->d * sizeof(float),
-                             (size_t)idx->d * sizeof(float), (size_t)nq_g, hipMemcpyDeviceToDevice, st));
-    q16 = c->q16;
+struct FuseLaunch {   // non-null state: fused top-k epilogue, no score matrix
+  uint32_t* state = nullptr;
+  uint64_t* cand = nullptr;
+  const float* thr = nullptr;   // thr[q * thr_stride]: lower bound of query q's k-th best score
+  int thr_stride = 0;
+  FuseLaunch at(int q0) const {
+    if (!state) return *this;
+    return FuseLaunch{state + (size_t)q0 * SCR_WORDS, cand + (size_t)q0 * CAND_CAP, thr + (size_t)q0 * thr_stride, thr_stride};
   }
+};
+
+// f32 queries as the batched kernels read them: [nq rounded up to `group`][ld], zero padded.
+// Returns the caller's buffer itself when it already has that shape.
+int stage_queries_f32(const svs_index* idx, Ctx* c, const float* q_dev, int nq, int group, const float** out, hipStream_t st) {
+  const int ld = idx->ld;
+  const int nq_pad = (nq + group - 1) / group * group;
+  if (nq_pad == nq && ld == idx->d && !(((uintptr_t)q_dev) & 15)) { *out = q_dev; return SVS_OK; }
+  int rc = grow_dev(&c->q16, &c->q16_cap, (size_t)nq_pad * ld);
+  if (rc != SVS_OK) return rc;
+  HIP_TRY(hipMemsetAsync(c->q16, 0, (size_t)nq_pad * ld * sizeof(float), st));
+  HIP_TRY(hipMemcpy2DAsync(c->q16, (size_t)ld * sizeof(float), q_dev, (size_t)idx->d * sizeof(float),
+                           (size_t)idx->d * sizeof(float), (size_t)nq, hipMemcpyDeviceToDevice, st));
+  *out = c->q16;
+  return SVS_OK;
+}
+
+template <class K>
+void launch_q16_kernel(K kernel, const svs_index* idx, const float* q16, int nq_g, int64_t n_rows, float* scores,
+                       int64_t sstride, int rows_per_block, FuseLaunch fl, hipStream_t st) {
+  const unsigned blocks = (unsigned)((n_rows + rows_per_block - 1) / rows_per_block);
+  const size_t lds = (size_t)idx->ld * 64 + (fl.state ? GEMM_FUSE_LDS : 0);   // 16 queries x ld floats
+  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(GEMM_WAVES * 64), lds, st,
+                     (const float*)idx->rows, q16, scores, n_rows, idx->ld, sstride, nq_g, rows_per_block,
+                     fl.state, (int)SCR_WORDS, fl.cand, (uint32_t)CAND_CAP, fl.thr, fl.thr_stride);
+}
+
+// q16: 16 staged queries ([16][ld]); rows [0, n_rows)
+int launch_scores_q16(const svs_index* idx, const float* q16, int nq_g, int64_t n_rows, float* scores,
+                      int64_t sstride, FuseLaunch fl, hipStream_t st) {
   static std::once_flag once;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute((const void*)gemm_f32_q16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2304 * 64);
-    (void)hipFuncSetAttribute((const void*)gemm_f32_q16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2304 * 64);
+    const int lds = 2304 * 64 + GEMM_FUSE_LDS;
+    (void)hipFuncSetAttribute((const void*)gemm_f32_q16r_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)gemm_f32_q16r_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)gemm_f32_q16_kernel<false, 2, GEMM_PF, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)gemm_f32_q16_kernel<false, 2, GEMM_PF, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   });
   const int variant = idx->variant.load();
-  // 1024 rows (6 MB at d = 1536) per workgroup amortise the 96 KiB query staging;
-  // measured 5.5 TB/s vs 5.2 (512 rows) / 5.2 (256 rows)
-  const int rows_per_block = variant == 4 ? 2048 : (variant == 5 ? 512 : 1024);
-  const unsigned blocks = (unsigned)((idx->n + rows_per_block - 1) / rows_per_block);
-  const size_t lds = (size_t)(ld / 16) * 64 * sizeof(v4f);
-  if (variant == 3 && ld % 256 == 0) {   // A/B: one 16-row tile per wave, 16-step (1 KiB per row) bursts
-    static std::once_flag once2;
-    std::call_once(once2, [] {
-      (void)hipFuncSetAttribute((const void*)gemm_f32_q16_kernel<false, 1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 2304 * 64);
-    });
-    hipLaunchKernelGGL((gemm_f32_q16_kernel<false, 1, 16>), dim3(blocks), dim3(GEMM_WAVES * 64), lds, st,
-                       (const float*)idx->rows, q16, scores, idx->n, ld, sstride, nq_g, rows_per_block);
-  } else if (variant == 2)
-    hipLaunchKernelGGL((gemm_f32_q16_kernel<true>), dim3(blocks), dim3(GEMM_WAVES * 64), lds, st,
-                       (const float*)idx->rows, q16, scores, idx->n, ld, sstride, nq_g, rows_per_block);
-  else
-    hipLaunchKernelGGL((gemm_f32_q16_kernel<false>), dim3(blocks), dim3(GEMM_WAVES * 64), lds, st,
-                       (const float*)idx->rows, q16, scores, idx->n, ld, sstride, nq_g, rows_per_block);
+  // 1024 rows (6 MB at d = 1536) per workgroup amortise the 96 KiB query staging; short
+  // row ranges (the fused path's prefix) take smaller blocks so that every CU gets one.
+  int rows_per_block = variant == 4 ? 2048 : (variant == 5 ? 512 : 1024);
+  while (rows_per_block > 64 && (n_rows + rows_per_block - 1) / rows_per_block < 512) rows_per_block /= 2;
+  if (variant == 3) {   // A/B: the 16x16x4 kernel (half-line loads)
+    if (fl.state) launch_q16_kernel(gemm_f32_q16_kernel<false, 2, GEMM_PF, true>, idx, q16, nq_g, n_rows, scores, sstride, rows_per_block, fl, st);
+    else launch_q16_kernel(gemm_f32_q16_kernel<false, 2, GEMM_PF, false>, idx, q16, nq_g, n_rows, scores, sstride, rows_per_block, fl, st);
+  } else {
+    if (fl.state) launch_q16_kernel(gemm_f32_q16r_kernel<true>, idx, q16, nq_g, n_rows, scores, sstride, rows_per_block, fl, st);
+    else launch_q16_kernel(gemm_f32_q16r_kernel<false>, idx, q16, nq_g, n_rows, scores, sstride, rows_per_block, fl, st);
+  }
   return SVS_OK;
 }
 
@@ -467,13 +491,6 @@ bool tiled_ok(const svs_index* idx) {
   return false;
 }
 
-struct FuseLaunch {   // non-null state: fused top-k epilogue, no score matrix
-  uint32_t* state = nullptr;
-  uint64_t* cand = nullptr;
-  const float* thr = nullptr;   // thr[q * thr_stride]: lower bound of query q's k-th best score
-  int thr_stride = 0;
-};
-
 template <int BN, bool FUSE, int EB, int BM = TG_BM>
 int launch_tiled_bn(const svs_index* idx, Ctx* c, int64_t n_rows, int nq, float* scores, int64_t sstride,
                     FuseLaunch fl, hipStream_t st) {
@@ -484,7 +501,7 @@ int launch_tiled_bn(const svs_index* idx, Ctx* c, int64_t n_rows, int nq, float*
                               tg_lds_bytes(BM, BN));
   });
   const unsigned gx = (unsigned)((n_rows + BM - 1) / BM), gy = (unsigned)((nq + BN - 1) / BN);
-  const uint8_t* Q = EB == 2 ? (const uint8_t*)c->qh : (EB == 1 ? (const uint8_t*)c->q8 : (const uint8_t*)c->q16);
+  const uint8_t* Q = EB == 2 ? (const uint8_t*)c->qh : (EB == 1 ? (const uint8_t*)c->q8 : (const uint8_t*)c->q_f32);
   hipLaunchKernelGGL((gemm_tiled_kernel<BN, FUSE, EB, BM>), dim3(gx, gy), dim3(TG_WAVES * 64), lds, st,
                      (const uint8_t*)idx->rows, Q, scores, n_rows, (int64_t)idx->ld * EB, sstride, nq,
                      fl.state, (int)SCR_WORDS, fl.cand, (uint32_t)CAND_CAP, fl.thr, fl.thr_stride,
@@ -513,19 +530,15 @@ int launch_scores_tiled(const svs_index* idx, Ctx* c, const float* q_dev, int64_
                         int64_t sstride, FuseLaunch fl, hipStream_t st, bool restage = true) {
   if (idx->dtype == SVS_DTYPE_F32) {
     // exact-f32 MFMA runs at the vector rate: 32 queries per pass keep the kernel HBM-bound
-    // (62 % of the matrix pipe); larger batches loop passes.
-    const int bn = nq <= 16 ? 32 : 32;
-    for (int q0 = 0; q0 < nq; q0 += bn) {
-      const int nq_g = std::min(bn, nq - q0);
-      int rc = grow_dev(&c->q16, &c->q16_cap, (size_t)bn * idx->ld);
+    // (62 % of the matrix pipe); larger batches are more passes of the same launch (grid y).
+    if (restage) {
+      const float* qs = nullptr;
+      int rc = stage_queries_f32(idx, c, q_dev, nq, 32, &qs, st);
       if (rc != SVS_OK) return rc;
-      HIP_TRY(hipMemsetAsync(c->q16, 0, (size_t)bn * idx->ld * sizeof(float), st));
-      HIP_TRY(hipMemcpy2DAsync(c->q16, (size_t)idx->ld * sizeof(float), q_dev + (size_t)q0 * idx->d, (size_t)idx->d * sizeof(float),
-                               (size_t)idx->d * sizeof(float), (size_t)nq_g, hipMemcpyDeviceToDevice, st));
-      rc = launch_tiled_bn<32, false, 4>(idx, c, n_rows, nq_g, scores + (size_t)q0 * sstride, sstride, FuseLaunch{}, st);
-      if (rc != SVS_OK) return rc;
+      c->q_f32 = qs;
     }
-    return SVS_OK;
+    return fl.state ? launch_tiled_bn<32, true, 4>(idx, c, n_rows, nq, scores, sstride, fl, st)
+                    : launch_tiled_bn<32, false, 4>(idx, c, n_rows, nq, scores, sstride, fl, st);
   }
   const int bn = nq <= 32 ? 32 : (nq <= 64 ? 64 : (nq <= 128 ? 128 : 256));
   const int nq_pad = (nq + bn - 1) / bn * bn;
@@ -578,18 +591,32 @@ int run_select(svs_index* idx, Ctx* c, const float* scores, int64_t n_eff, int64
 // rows whose exact k-th best seeds the fused epilogue's thresholds: about k * n / prefix
 // candidates per query survive, so the prefix grows with n (n/64 -> ~64 k survivors)
 // Materialised scores of nq queries: scores[q][sstride] (the non-fused score stage).
-int launch_scores_any(svs_index* idx, Ctx* c, const float* q_dev, int nq, float* scores, int64_t sstride, hipStream_t st) {
+bool uses_q16(const svs_index* idx, int nq) {
+  return nq >= 2 && batch_kernel_ok(idx) && (nq <= GQ || idx->variant.load() == 5 || !tiled_ok(idx));
+}
+
+// rows [0, n_rows); fl.state != null: fused epilogue (batched kernels only); restage == false
+// reuses the queries staged by the previous call on this context.
+int launch_scores_any(svs_index* idx, Ctx* c, const float* q_dev, int64_t n_rows, int nq, float* scores, int64_t sstride,
+                      FuseLaunch fl, hipStream_t st, bool restage = true) {
   int rc;
-  // f32: up to 16 queries -> the 16-query streaming kernel (5.4 TB/s, 1.14 ms at 1M x 1536);
-  // more -> the tiled kernel at 32 queries per pass (1.30 ms: bound by the f32 MFMA rate)
-  if (nq >= 2 && batch_kernel_ok(idx) && (nq <= GQ || idx->variant.load() == 5 || !tiled_ok(idx))) {
+  // f32: up to 16 queries -> the 16-query streaming kernel; more -> the tiled kernel at 32
+  // queries per pass (bound by the f32 MFMA rate)
+  if (uses_q16(idx, nq)) {
+    if (restage) {
+      const float* qs = nullptr;
+      if ((rc = stage_queries_f32(idx, c, q_dev, nq, GQ, &qs, st)) != SVS_OK) return rc;
+      c->q_f32 = qs;
+    }
     for (int q0 = 0; q0 < nq; q0 += GQ) {
-      rc = launch_scores_q16(idx, c, q_dev + (size_t)q0 * idx->d, std::min(GQ, nq - q0), scores + (size_t)q0 * sstride, sstride, st);
+      rc = launch_scores_q16(idx, c->q_f32 + (size_t)q0 * idx->ld, std::min(GQ, nq - q0), n_rows,
+                             scores ? scores + (size_t)q0 * sstride : nullptr, sstride, fl.at(q0), st);
       if (rc != SVS_OK) return rc;
     }
   } else if (nq >= 2 && tiled_ok(idx)) {
-    if ((rc = launch_scores_tiled(idx, c, q_dev, idx->n, nq, scores, sstride, FuseLaunch{}, st)) != SVS_OK) return rc;
+    if ((rc = launch_scores_tiled(idx, c, q_dev, n_rows, nq, scores, sstride, fl, st, restage)) != SVS_OK) return rc;
   } else {
+    if (fl.state || n_rows != idx->n) return fail(SVS_ERR_INVALID, "internal: single-query kernels have no fused / prefix form");
     for (int qi = 0; qi < nq; ++qi) {
       rc = launch_scores(idx, c, q_dev + (size_t)qi * idx->d, scores + (size_t)qi * sstride, st);
       if (rc != SVS_OK) return rc;
@@ -609,10 +636,13 @@ int enqueue_search(svs_index* idx, Ctx* c, const float* q_dev, int nq, int k, in
   const int64_t n = idx->n;
   int rc;
   const bool path_a = k > 0 && n > SORT_CAP && count <= SEL_KMAX;
-  // Fused top-k epilogue (no score matrix): batched f16 GEMM only; a query whose
-  // candidate list overflows comes back marked and is re-run by the caller.
-  const bool fused = allow_fused && path_a && nq >= 64 && n >= 8 * FUSE_PREFIX_MIN && tiled_ok(idx) &&
-                     idx->dtype != SVS_DTYPE_F32 &&
+  // Fused top-k epilogue (no score matrix) for the batched kernels; a query whose
+  // candidate list overflows comes back marked and is re-run by the caller.  The prefix
+  // pass costs ~60 us whatever the batch: measured break-even is 16 queries for f32
+  // (13.2 k vs 12.7 k queries/s at 16, 26.9 k vs 24.6 k at 256; 8 queries: 6.4 k vs 6.5 k).
+  const bool batched = uses_q16(idx, nq) || (nq >= 2 && tiled_ok(idx));
+  const bool fused = allow_fused && path_a && batched && nq >= (idx->dtype == SVS_DTYPE_F32 ? 16 : 64) &&
+                     n >= 8 * FUSE_PREFIX_MIN && (int64_t)n < ((int64_t)1 << 32) &&
                      count <= 256 && idx->dead_list.empty() && idx->variant.load() != 6;
   const int64_t n_mat = fused ? fuse_prefix_rows(n) : n;     // rows of the materialised score matrix
   const int64_t sstride = (n_mat + 3) & ~(int64_t)3;         // float4-aligned score vectors
@@ -642,16 +672,16 @@ int enqueue_search(svs_index* idx, Ctx* c, const float* q_dev, int nq, int k, in
     // 1. thresholds: exact k-th best of the first FUSE_PREFIX_ROWS rows, per query
     if ((rc = grow_dev(&c->pref_s, &c->pref_s_cap, (size_t)nq * count)) != SVS_OK) return rc;
     if ((rc = grow_dev(&c->pref_r, &c->pref_r_cap, (size_t)nq * count)) != SVS_OK) return rc;
-    if ((rc = launch_scores_tiled(idx, c, q_dev, n_mat, nq, c->scores, sstride, FuseLaunch{}, st)) != SVS_OK) return rc;
+    if ((rc = launch_scores_any(idx, c, q_dev, n_mat, nq, c->scores, sstride, FuseLaunch{}, st)) != SVS_OK) return rc;
     if ((rc = run_select(idx, c, c->scores, n_mat, sstride, nq, count, count, c->pref_s, c->pref_r, st, idx->row_offset)) != SVS_OK) return rc;
     // 2. the whole corpus, keeping only scores >= threshold
     FuseLaunch fl{c->hist, c->cand, c->pref_s + (count - 1), count};
-    if ((rc = launch_scores_tiled(idx, c, q_dev, n, nq, nullptr, 0, fl, st, false)) != SVS_OK) return rc;
+    if ((rc = launch_scores_any(idx, c, q_dev, n, nq, nullptr, 0, fl, st, false)) != SVS_OK) return rc;
     if (timed) HIP_TRY(hipEventRecord(ev.e1, st));
     hipLaunchKernelGGL(select_final_kernel, dim3(nq), dim3(FINAL_THREADS), 0, st, (const float*)nullptr, n, (int64_t)0, k, count, 3,
                        c->hist, c->cand, idx->row_offset, out_s, out_r);
   } else {
-    if ((rc = launch_scores_any(idx, c, q_dev, nq, c->scores, sstride, st)) != SVS_OK) return rc;
+    if ((rc = launch_scores_any(idx, c, q_dev, n, nq, c->scores, sstride, FuseLaunch{}, st)) != SVS_OK) return rc;
     if (!idx->dead_list.empty())   // tombstoned rows can never be returned
       hipLaunchKernelGGL(mask_dead_rows_kernel, dim3(64), dim3(256), 0, st, c->scores, sstride, nq, idx->dead_dev,
                          (int64_t)idx->dead_list.size());
@@ -1128,7 +1158,7 @@ int32_t svs_index_top_pairs(svs_index* idx, int32_t k, float* out_scores, int64_
   const int chunk = 1024;
   for (int64_t q0 = 0; q0 < n; q0 += chunk) {
     const int nq = (int)std::min<int64_t>(chunk, n - q0);
-    if ((rc = launch_scores_any(idx, c, qall + q0 * idx->d, nq, S + q0 * np, np, st)) != SVS_OK) return rc;
+    if ((rc = launch_scores_any(idx, c, qall + q0 * idx->d, idx->n, nq, S + q0 * np, np, FuseLaunch{}, st)) != SVS_OK) return rc;
   }
   hipLaunchKernelGGL(mask_upper_triangle_kernel, dim3(4096), dim3(256), 0, st, S, n, np);
   if (!idx->dead_list.empty())
