@@ -35,6 +35,17 @@
 
 namespace svs {
 
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+#ifdef TG_TRACE   // tools/gemm_trace.hip only: cycle stamps of one wave's k-loop phases
+__device__ long long* tg_trace_buf;
+#define TG_STAMP(slot) do { if (tg_tr) tg_trace_buf[(wave * 64 + s) * 4 + (slot)] = clock64(); } while (0)
+#define TG_STAMP_BLOCK(slot) do { if (blockIdx.x == 1000 && blockIdx.y == 0 && (threadIdx.x & 63) == 0) tg_trace_buf[8 * 64 * 4 + (threadIdx.x >> 6) * 4 + (slot)] = clock64(); } while (0)
+#else
+#define TG_STAMP(slot) do { } while (0)
+#define TG_STAMP_BLOCK(slot) do { } while (0)
+#endif
+
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int TG_BM = 128;  // corpus rows per workgroup tile (256 for the MFMA-bound BN = 256 panels)
@@ -124,6 +135,7 @@ __global__ __launch_bounds__(TG_WAVES * 64) void gemm_tiled_kernel(
   constexpr int MT = TM / 16, NT = TN / 16; // MFMA tiles per wave
   static_assert(TM % 16 == 0 && TN % 16 == 0, "wave tile must be whole MFMA tiles");
   extern __shared__ u32x4 tg_lds[];
+  TG_STAMP_BLOCK(0);
   // layout: A buffers [NBUF][128 rows][8 chunks], then B buffers [NBUF][BN rows][8 chunks]
   constexpr int NBUF = tg_nbuf(BM, BN);   // 3 when it fits the 160 KiB LDS, else 2 (256 x 256 tiles)
   auto ldsA = [&](int b) { return tg_lds + b * (BM * 8); };
@@ -134,8 +146,27 @@ __global__ __launch_bounds__(TG_WAVES * 64) void gemm_tiled_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int r16 = lane & 15, g = lane >> 4;
-  const int64_t row0 = (int64_t)blockIdx.x * BM;
-  const int q0 = blockIdx.y * BN;
+  // Workgroups are dispatched in linear order (x fastest) round-robin over the 8 XCDs, each
+  // with its own L2.  With several query tiles per row tile (grid y > 1) the tiles that share
+  // a row tile are mapped to consecutive slots of ONE XCD, so the corpus tile comes from HBM
+  // once and from that L2 for the other query tiles (instead of once per query tile).
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (gridDim.y > 1) {
+    const int gx = gridDim.x, gy = gridDim.y;
+    const int id = by * gx + bx;
+    const int full = (gx >> 3) << 3;            // row tiles in whole groups of 8
+    if (id < full * gy) {
+      const int grp = id / (8 * gy), within = id - grp * 8 * gy;
+      bx = grp * 8 + (within & 7);
+      by = within >> 3;
+    } else {
+      const int rem = gx - full, t = id - full * gy;
+      bx = full + t % rem;
+      by = t / rem;
+    }
+  }
+  const int64_t row0 = (int64_t)bx * BM;
+  const int q0 = by * BN;
   const int ksteps = (int)(ldb / TG_BKB);
 
   f32x4_t acc[MT][NT];
@@ -162,11 +193,18 @@ __global__ __launch_bounds__(TG_WAVES * 64) void gemm_tiled_kernel(
     srcB.stage(1, ldsB(1));
   }
   int cur = 0;
+  TG_STAMP_BLOCK(1);
+#ifdef TG_TRACE
+  const bool tg_tr = blockIdx.x == 1000 && blockIdx.y == 0 && lane == 0 && ksteps <= 64;
+#endif
   for (int s = 0; s < ksteps; ++s) {
+    TG_STAMP(0);
     // retire step s's DMA: everything but the (AHEAD - 1) younger steps
     if (AHEAD > 1 && s + 1 < ksteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_STAGE) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TG_STAMP(1);
     __builtin_amdgcn_s_barrier();
+    TG_STAMP(2);
     if (s + AHEAD < ksteps) {
       const int nb = cur >= 1 ? cur - 1 : NBUF - 1;   // (s + AHEAD) % NBUF: the buffer read in step s - 1
       srcA.stage(s + AHEAD, ldsA(nb));
@@ -230,32 +268,34 @@ __global__ __launch_bounds__(TG_WAVES * 64) void gemm_tiled_kernel(
           }
       }
     } else {
-      const long* A8 = (const long*)A;
-      const long* B8 = (const long*)B;
+      // CDNA4's v_mfma_f32_16x16x128_f8f6f4 (e4m3 x e4m3, no block scales): one instruction
+      // per 128-byte stage, 2x the per-clock rate of the 16x16x32 fp8 form (which runs at the
+      // f16 rate on gfx950).  Lane (r16, g) supplies 32 consecutive k bytes = chunks 2g, 2g+1
+      // of its row -- the same k set for both operands.
+      i32x8 fa[MT], fb[NT];
 #pragma unroll
-      for (int kq = 0; kq < 4; ++kq) {   // four 32-wide k-quarters; lane holds bytes 8g..8g+7 = half a chunk
-        long fa[MT], fb[NT];
-        const int chunk = 2 * kq + (g >> 1), half = g & 1;
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          const int r = wm * TM + i * 16 + r16;
-          fa[i] = A8[(r * 8 + (chunk ^ tg_swz(r))) * 2 + half];
-        }
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const int r = wn * TN + j * 16 + r16;
-          fb[j] = B8[(r * 8 + (chunk ^ tg_swz(r))) * 2 + half];
-        }
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      for (int i = 0; i < MT; ++i) {
+        const int r = wm * TM + i * 16 + r16;
+        const u32x4 lo = A[r * 8 + ((2 * g) ^ tg_swz(r))], hi = A[r * 8 + ((2 * g + 1) ^ tg_swz(r))];
+        fa[i] = (i32x8){(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
       }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int r = wn * TN + j * 16 + r16;
+        const u32x4 lo = B[r * 8 + ((2 * g) ^ tg_swz(r))], hi = B[r * 8 + ((2 * g + 1) ^ tg_swz(r))];
+        fb[j] = (i32x8){(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[i], fb[j], acc[i][j], 0, 0, 0, 0, 0, 0);
     }
+    TG_STAMP(3);
     cur = cur + 1 < NBUF ? cur + 1 : 0;
   }
 
+  TG_STAMP_BLOCK(2);
   // D layout: column (query) = lane & 15, rows 4 g + r of each 16-row tile
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
@@ -274,15 +314,32 @@ __global__ __launch_bounds__(TG_WAVES * 64) void gemm_tiled_kernel(
         }
       }
       if constexpr (FUSE) {
-        uint32_t* hdr = fstate_words + (int64_t)query * fstate_stride;
-        uint64_t* cq = fcand + (int64_t)query * fcap;
+        // A lane holds MT * 4 scores of ONE query here.  It counts its survivors first and
+        // claims all their slots with ONE atomic (a returning atomic per surviving score made
+        // each wave wait ~40 L2 round trips per tile: 24 of the 72 us a 256x256 tile took).
         const float thr = fthr[(int64_t)query * fthr_stride];
+        uint32_t cnt = 0;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
           const int64_t ob = row0 + wm * TM + i * 16 + 4 * g;
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (ob + r < n) fuse_offer(hdr, cq, fcap, thr, acc[i][j][r], (uint32_t)(ob + r));
+          for (int r = 0; r < 4; ++r) cnt += (acc[i][j][r] >= thr && ob + r < n) ? 1u : 0u;
+        }
+        if (cnt) {
+          uint32_t slot = atomicAdd(fstate_words + (int64_t)query * fstate_stride, cnt);
+          uint64_t* cq = fcand + (int64_t)query * fcap;
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+            const int64_t ob = row0 + wm * TM + i * 16 + 4 * g;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float v = acc[i][j][r];
+              if (v >= thr && ob + r < n) {
+                if (slot < fcap) cq[slot] = ((uint64_t)score_key(v) << 32) | (uint32_t)(ob + r);
+                ++slot;
+              }
+            }
+          }
         }
       } else {
         float* o = scores + (int64_t)query * sstride;
@@ -297,6 +354,7 @@ __global__ __launch_bounds__(TG_WAVES * 64) void gemm_tiled_kernel(
       }
     }
   }
+  TG_STAMP_BLOCK(3);
 }
 
 }  // namespace svs
