@@ -197,6 +197,70 @@ __global__ __launch_bounds__(TG_WAVES * 64) void gemm_tiled_kernel(
 #ifdef TG_TRACE
   const bool tg_tr = blockIdx.x == 1000 && blockIdx.y == 0 && lane == 0 && ksteps <= 64;
 #endif
+  // A lane's fragment of one 16-row tile and one 128-byte stage: two 16-byte chunks.
+  //   f16: chunk 4h + g = halves 8g..8g+7 of the 32-wide k-half h (one 16x16x32 MFMA each)
+  //   f32: chunk 4h + g = floats 4g..4g+3 of the 16-wide sub-step h; the four components feed
+  //        four exact v_mfma_f32_16x16x4_f32 whose k-slot g maps to column 16h + 4g + e
+  //   fp8: chunks 2g, 2g + 1 = 32 consecutive k bytes: ONE v_mfma_f32_16x16x128_f8f6f4
+  //        (CDNA4; e4m3 x e4m3, no block scales), 2x the per-clock rate of the 16x16x32 fp8
+  //        form, which runs at the f16 rate on gfx950
+  // The k map is the same for both operands, so any permutation inside it cancels.
+  u32x4 fa[2][MT], fb[2][NT];
+  auto read_frags = [&](const u32x4* A, const u32x4* B) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int chunk = EB == 1 ? 2 * g + h : 4 * h + g;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int r = wm * TM + i * 16 + r16;
+        fa[h][i] = A[r * 8 + (chunk ^ tg_swz(r))];
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int r = wn * TN + j * 16 + r16;
+        fb[h][j] = B[r * 8 + (chunk ^ tg_swz(r))];
+      }
+    }
+  };
+  auto mma = [&]() {
+    if constexpr (EB == 2) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, fa[h][i]), __builtin_bit_cast(h8, fb[h][j]),
+                                                               acc[i][j], 0, 0, 0);
+    } else if constexpr (EB == 4) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const v4f x = __builtin_bit_cast(v4f, fa[h][i]), y = __builtin_bit_cast(v4f, fb[h][j]);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, y.x, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, y.y, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, y.z, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, y.w, acc[i][j], 0, 0, 0);
+          }
+    } else {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const u32x4 al = fa[0][i], ah = fa[1][i], bl = fb[0][j], bh = fb[1][j];
+          const i32x8 x = {(int)al.x, (int)al.y, (int)al.z, (int)al.w, (int)ah.x, (int)ah.y, (int)ah.z, (int)ah.w};
+          const i32x8 y = {(int)bl.x, (int)bl.y, (int)bl.z, (int)bl.w, (int)bh.x, (int)bh.y, (int)bh.z, (int)bh.w};
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(x, y, acc[i][j], 0, 0, 0, 0, 0, 0);
+        }
+    }
+  };
+  // (Tried: the second wave of each SIMD one phase behind the first -- multiplying the previous
+  // step's fragments while the first wave reads -- so that the LDS pipe and the matrix pipe
+  // overlap instead of taking turns: -4 % cycles on constant operands, nothing on real data,
+  // where the chip is at its power limit and the clock, not the schedule, sets the time.)
   for (int s = 0; s < ksteps; ++s) {
     TG_STAMP(0);
     // retire step s's DMA: everything but the (AHEAD - 1) younger steps
@@ -210,87 +274,8 @@ __global__ __launch_bounds__(TG_WAVES * 64) void gemm_tiled_kernel(
       srcA.stage(s + AHEAD, ldsA(nb));
       srcB.stage(s + AHEAD, ldsB(nb));
     }
-    const u32x4* A = ldsA(cur);
-    const u32x4* B = ldsB(cur);
-    if constexpr (EB == 2) {
-      // both 32-wide k-halves' fragments are requested before the first MFMA: the second
-      // half's LDS latency hides under the first half's MFMAs (lane holds halves 8g..8g+7
-      // of a half = one 16-byte chunk)
-      h8 fa[2][MT], fb[2][NT];
-#pragma unroll
-      for (int kh = 0; kh < 2; ++kh) {
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          const int r = wm * TM + i * 16 + r16;
-          fa[kh][i] = __builtin_bit_cast(h8, A[r * 8 + ((4 * kh + g) ^ tg_swz(r))]);
-        }
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const int r = wn * TN + j * 16 + r16;
-          fb[kh][j] = __builtin_bit_cast(h8, B[r * 8 + ((4 * kh + g) ^ tg_swz(r))]);
-        }
-      }
-#pragma unroll
-      for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[kh][i], fb[kh][j], acc[i][j], 0, 0, 0);
-    } else if constexpr (EB == 4) {
-      // exact f32: v_mfma_f32_16x16x4_f32 (bit-for-bit an fmaf chain).  A 128-byte stage is 32
-      // floats per row; lane (r16, g) takes chunk 4t + g of sub-step t and its four components
-      // feed four MFMAs whose k-slot g maps to column 16t + 4g + e -- the same map for both
-      // operands, so the permutation cancels.
-      const v4f* A4 = (const v4f*)A;
-      const v4f* B4 = (const v4f*)B;
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        v4f fa[MT], fb[NT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          const int r = wm * TM + i * 16 + r16;
-          fa[i] = A4[r * 8 + ((4 * t + g) ^ tg_swz(r))];
-        }
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const int r = wn * TN + j * 16 + r16;
-          fb[j] = B4[r * 8 + ((4 * t + g) ^ tg_swz(r))];
-        }
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
-          }
-      }
-    } else {
-      // CDNA4's v_mfma_f32_16x16x128_f8f6f4 (e4m3 x e4m3, no block scales): one instruction
-      // per 128-byte stage, 2x the per-clock rate of the 16x16x32 fp8 form (which runs at the
-      // f16 rate on gfx950).  Lane (r16, g) supplies 32 consecutive k bytes = chunks 2g, 2g+1
-      // of its row -- the same k set for both operands.
-      i32x8 fa[MT], fb[NT];
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int r = wm * TM + i * 16 + r16;
-        const u32x4 lo = A[r * 8 + ((2 * g) ^ tg_swz(r))], hi = A[r * 8 + ((2 * g + 1) ^ tg_swz(r))];
-        fa[i] = (i32x8){(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
-      }
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int r = wn * TN + j * 16 + r16;
-        const u32x4 lo = B[r * 8 + ((2 * g) ^ tg_swz(r))], hi = B[r * 8 + ((2 * g + 1) ^ tg_swz(r))];
-        fb[j] = (i32x8){(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
-      }
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[i], fb[j], acc[i][j], 0, 0, 0, 0, 0, 0);
-    }
+    read_frags(ldsA(cur), ldsB(cur));
+    mma();
     TG_STAMP(3);
     cur = cur + 1 < NBUF ? cur + 1 : 0;
   }

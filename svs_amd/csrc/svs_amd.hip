@@ -289,7 +289,7 @@ int stage_queries_f16(const svs_index* idx, Ctx* c, const float* q, int nq, int 
   int rc = grow_dev(&c->qh, &c->qh_cap, (size_t)rows_alloc * idx->ld);
   if (rc != SVS_OK) return rc;
   if (rows_alloc > nq) HIP_TRY(hipMemsetAsync(c->qh, 0, (size_t)rows_alloc * idx->ld * sizeof(_Float16), st));
-  hipLaunchKernelGGL(convert_queries_f16_kernel, dim3(std::min(64, nq * 4)), dim3(256), 0, st, q, nq, idx->d, c->qh, idx->ld);
+  hipLaunchKernelGGL(convert_queries_f16_kernel, dim3((unsigned)std::min<int64_t>(2048, ((int64_t)nq * idx->ld + 255) / 256)), dim3(256), 0, st, q, nq, idx->d, c->qh, idx->ld);
   return SVS_OK;
 }
 

@@ -3,16 +3,24 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#include <algorithm>
+#include <cstdlib>
 #include "../svs_amd/csrc/select.h"
 #include "../svs_amd/csrc/gemm_tiled.h"
 using namespace svs;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1;} } while (0)
 template <int BN, int EB, int BM, bool FUSE = false>
-int run(const char* name, int64_t n, int d, int nq) {
+int run(const char* name, int64_t n, int d, int nq, bool random_data = false) {
   const int64_t ldb = (int64_t)d * EB;
   uint8_t *M, *Q; float* S; long long* tr;
   CK(hipMalloc(&M, n * ldb)); CK(hipMalloc(&Q, (size_t)nq * ldb)); CK(hipMalloc(&S, (size_t)nq * n * 4)); CK(hipMalloc(&tr, (8 * 64 * 4 + 64) * 8));
-  CK(hipMemset(M, 0x3c, n * ldb)); CK(hipMemset(Q, 0x3c, nq * ldb)); CK(hipMemset(tr, 0, (8 * 64 * 4 + 64) * 8));
+  CK(hipMemset(M, 0x3c, n * ldb)); CK(hipMemset(Q, 0x3c, nq * ldb));
+  if (random_data) {   // random bytes with the exponent bits kept small: realistic operand toggling
+    std::vector<uint8_t> h((size_t)64 << 20);
+    for (size_t i = 0; i < h.size(); ++i) h[i] = (uint8_t)(rand() & (EB == 2 ? ((i & 1) ? 0xa7 : 0xff) : 0xb7));
+    for (size_t off = 0; off < (size_t)(n * ldb); off += h.size()) CK(hipMemcpy(M + off, h.data(), std::min(h.size(), (size_t)(n * ldb) - off), hipMemcpyHostToDevice));
+    CK(hipMemcpy(Q, h.data(), (size_t)nq * ldb, hipMemcpyHostToDevice));
+  } CK(hipMemset(tr, 0, (8 * 64 * 4 + 64) * 8));
   CK(hipMemcpyToSymbol(HIP_SYMBOL(tg_trace_buf), &tr, sizeof(tr)));
   const int lds = tg_lds_bytes(BM, BN);
   CK(hipFuncSetAttribute((const void*)gemm_tiled_kernel<BN, FUSE, EB, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -49,8 +57,9 @@ int run(const char* name, int64_t n, int d, int nq) {
   return 0;
 }
 int main() {
-  if (run<256, 2, 256, true>("f16 256x256 fused, nq=1024", 1000000, 1536, 1024)) return 1;
-  if (run<256, 2, 256, false>("f16 256x256 materialised, nq=1024", 1000000, 1536, 1024)) return 1;
-  if (run<256, 1, 256, true>("fp8 256x256 fused, nq=1024", 1000000, 1536, 1024)) return 1;
+  if (run<256, 2, 256, true>("f16 256x256 fused, random operands", 1000000, 1536, 1024, true)) return 1;
+  if (run<256, 2, 256, true>("f16 256x256 fused, constant operands", 1000000, 1536, 1024, false)) return 1;
+  if (run<256, 1, 256, true>("fp8 256x256 fused, random operands", 1000000, 1536, 1024, true)) return 1;
+  if (run<256, 1, 256, true>("fp8 256x256 fused, constant operands", 1000000, 1536, 1024, false)) return 1;
   return 0;
 }
