@@ -201,15 +201,18 @@ __global__ __launch_bounds__(TG_WAVES * 64) void gemm_tiled_kernel(
   //   f16: chunk 4h + g = halves 8g..8g+7 of the 32-wide k-half h (one 16x16x32 MFMA each)
   //   f32: chunk 4h + g = floats 4g..4g+3 of the 16-wide sub-step h; the four components feed
   //        four exact v_mfma_f32_16x16x4_f32 whose k-slot g maps to column 16h + 4g + e
-  //   fp8: chunks 2g, 2g + 1 = 32 consecutive k bytes: ONE v_mfma_f32_16x16x128_f8f6f4
+  //   fp8: the same two chunks are the lane's 32 k bytes of ONE v_mfma_f32_16x16x128_f8f6f4
   //        (CDNA4; e4m3 x e4m3, no block scales), 2x the per-clock rate of the 16x16x32 fp8
-  //        form, which runs at the f16 rate on gfx950
+  //        form, which runs at the f16 rate on gfx950.  (Chunks 2g, 2g + 1 -- consecutive k --
+  //        would be the natural choice, but ds_read_b128 serves lanes in the groups
+  //        {0-3, 12-15, 20-27}, ... and that pairing put two lanes of a group on every bank:
+  //        SQ_LDS_BANK_CONFLICT was half of the LDS cycles.)
   // The k map is the same for both operands, so any permutation inside it cancels.
   u32x4 fa[2][MT], fb[2][NT];
   auto read_frags = [&](const u32x4* A, const u32x4* B) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int chunk = EB == 1 ? 2 * g + h : 4 * h + g;
+      const int chunk = 4 * h + g;
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         const int r = wm * TM + i * 16 + r16;
