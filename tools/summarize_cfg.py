@@ -18,8 +18,14 @@ src, dst = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
 
 
 def newest(pat):
-    f = sorted(glob.glob(pat), key=os.path.getsize)
-    return f[-1] if f else None
+    """The profiled program's own file of the most recent run: gpurun merges every run's files
+    into the same directory (one set per process id), so take the files written with the
+    latest merge and, among those, the largest (helper processes leave near-empty ones)."""
+    f = glob.glob(pat)
+    if not f:
+        return None
+    t = max(os.path.getmtime(x) for x in f)
+    return max((x for x in f if os.path.getmtime(x) >= t - 120), key=os.path.getsize)
 
 
 short = lambda k: k.split("(")[0]

@@ -11,7 +11,12 @@ src = os.path.join(root, "gpurun_out")
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 
-newest = lambda pat: sorted(glob.glob(pat), key=os.path.getmtime)[-1]
+def newest(pat):
+    # latest merge's files; among those the largest (helper processes leave near-empty ones)
+    f = glob.glob(pat)
+    t = max(os.path.getmtime(x) for x in f)
+    return max((x for x in f if os.path.getmtime(x) >= t - 120), key=os.path.getsize)
+
 stats = newest(os.path.join(src, f"prof_{tag}_trace", "*", "*_kernel_stats.csv"))
 shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
 kern = {}
