@@ -7,6 +7,12 @@
 // (BASELINE.json north_star) while staying HBM-bound: 16 x 2 flop per 4 corpus
 // bytes = 8 flop/B, far below the f32 ridge.
 //
+// Two kernels compute it.  gemm_f32_q16r_kernel (second half of this file, 4x4x1 MFMA,
+// whole-line loads) is the product path; gemm_f32_q16_kernel (16x16x4 MFMA, half-line
+// loads) is the first design, kept behind svs_index_set_variant(3) as the measured
+// alternative (1.21 vs 1.10 ms per 16 queries at 1M x 1536).
+//
+// ---- gemm_f32_q16_kernel ----
 // Arithmetic: v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate: bit-for-bit an
 // fmaf chain, no reduced precision).  Per wave and 16-row tile the A operand is
 // the corpus (lane l: row l&15, k-slot l>>4) and the B operand the queries

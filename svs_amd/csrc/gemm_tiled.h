@@ -2,17 +2,19 @@
 //     S[j][i] = sum_d M8/16[i,d] * Q8/16[j,d]   (f32 accumulate; x scales for fp8)
 // for BASELINE.json configs[2] (1M x 1536 f16, 1024 queries) and configs[4]
 // (10M x 3072 fp8, 256 queries).  EB = bytes per element: 2 -> half operands on
-// v_mfma_f32_16x16x32_f16, 1 -> e4m3 operands on v_mfma_f32_16x16x32_fp8_fp8,
+// v_mfma_f32_16x16x32_f16, 1 -> e4m3 operands on v_mfma_f32_16x16x128_f8f6f4 (CDNA4),
 // 4 -> exact f32 on v_mfma_f32_16x16x4_f32, 16-32 queries per corpus pass (a
 // k-step is always 128 BYTES per row: 32 floats, 64 halves or 128 fp8).  The reference's
 // nearest analogue is its np.dot(M, M.T) (src/svs/kb.py:1651); a query batch is
 // by definition a loop of np.dot(M, q) calls (src/svs/kb.py:1623).
 //
 // Roofline: with a BN-query panel per workgroup column the corpus is read
-// ceil(nq/BN) times: HBM-bound for small panels (BN = 32: 8 % MFMA), MFMA-bound
-// from BN = 256 up (AI = 256 flop per corpus byte).
+// ceil(nq/BN) times (from HBM once: the panels of a row tile share an XCD's L2):
+// HBM-bound for small panels (BN = 32: 8 % MFMA), MFMA-bound from BN = 256 up
+// (AI = 256 flop per corpus byte) -- in practice bound by the chip's power limit
+// (MfmaUtil 40-46 % at 1.7-1.9 GHz).
 //
-// Structure (gfx950): workgroup tile = 128 corpus rows x BN queries, BK = 64 halves
+// Structure (gfx950): workgroup tile = BM (128 or 256) corpus rows x BN queries, BK = 64 halves
 // (exactly ONE 128-byte line per row per k-step), 8 waves.  Both operand tiles
 // are staged HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPRs, every
 // wave instruction moves 8 rows x 128 B of whole lines) through a three-buffer
@@ -22,8 +24,9 @@
 // the SOURCE address: physical 16-byte chunk c of row r holds global chunk
 // c ^ ((r >> 1) & 7), and fragment reads apply the same XOR -- conflict-free
 // ds_read_b128 for every 16-lane group of v_mfma_f32_16x16x32_f16 operands.
-// Wave tile = TM x TN (64x64 at BN = 256): A and B fragments are read once per
-// k-half and reused across the 4x4 MFMA tiles.
+// Wave tile = TM x TN (128 x 64 for the 256 x 256 workgroup tile): A and B fragments
+// are read once per k-step and reused across the 8 x 4 MFMA tiles.  With BM = BN = 256
+// the two-buffer ring fills the 160 KiB LDS (one workgroup per CU).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
