@@ -211,56 +211,77 @@ __global__ __launch_bounds__(TG_WAVES * 64) void gemm_tiled_kernel(
   //        {0-3, 12-15, 20-27}, ... and that pairing put two lanes of a group on every bank:
   //        SQ_LDS_BANK_CONFLICT was half of the LDS cycles.)
   // The k map is the same for both operands, so any permutation inside it cancels.
-  u32x4 fa[2][MT], fb[2][NT];
-  auto read_frags = [&](const u32x4* A, const u32x4* B) {
+  //
+  // Schedule of one k-step.  Left alone, hipcc keeps two A fragments live and emits
+  // "2 ds_reads, s_waitcnt lgkmcnt(0), 8 MFMAs" eight times per k-step: the LDS latency is
+  // exposed before every 128 cycles of matrix work (k-loop trace: 3,360 cycles of a k-step
+  // spent issuing 2,048 cycles of MFMA).  So the order is spelled out: all B fragments and
+  // the first DEPTH A fragments are requested up front, each A fragment's slot of a small
+  // ring is refilled right after the MFMAs that consumed it were issued -- DEPTH - 1
+  // fragments (~200 cycles of MFMA) before it is needed -- and a scheduling barrier after
+  // every fragment keeps the compiler from folding the reads back next to their use.
+  // (hipcc still waits lgkmcnt(0) each time -- with LDS-DMA in flight its waitcnt pass never
+  // counts LDS reads -- but a hand-counted version with inline-asm ds_reads measured the same:
+  // what remains of the k-step is the barrier and the restart after it, not these waits.)
+  constexpr int NA = EB == 1 ? MT : 2 * MT;            // A-fragment units per k-step, in order of use
+  constexpr int APER = EB == 1 ? 2 : 1;                // 16-byte reads per unit (fp8: both chunks)
+  constexpr int DEPTH = NA < (EB == 1 ? 3 : 4) ? NA : (EB == 1 ? 3 : 4);
+  auto compute_step = [&](const u32x4* A, const u32x4* B) {
+    u32x4 fb[2][NT];
+    u32x4 ring[DEPTH][APER];
+    auto read_a = [&](int unit, u32x4 (&dst)[APER]) {
+      const int i = EB == 1 ? unit : unit % MT;
+      const int r = wm * TM + i * 16 + r16;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int chunk = 4 * h + g;
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int r = wm * TM + i * 16 + r16;
-        fa[h][i] = A[r * 8 + (chunk ^ tg_swz(r))];
+      for (int c = 0; c < APER; ++c) {
+        const int h = EB == 1 ? c : unit / MT;
+        dst[c] = A[r * 8 + ((4 * h + g) ^ tg_swz(r))];
       }
+    };
+    auto read_b = [&](int h) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int r = wn * TN + j * 16 + r16;
-        fb[h][j] = B[r * 8 + (chunk ^ tg_swz(r))];
+        fb[h][j] = B[r * 8 + ((4 * h + g) ^ tg_swz(r))];
       }
-    }
-  };
-  auto mma = [&]() {
-    if constexpr (EB == 2) {
+    };
+    read_b(0);
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+    for (int u = 0; u < DEPTH; ++u) read_a(u, ring[u]);
+    read_b(1);
+    if constexpr (NA > DEPTH) __builtin_amdgcn_sched_barrier(0);   // (small tiles: nothing to pipeline, the compiler's order is fine)
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+    for (int u = 0; u < NA; ++u) {
+      const int slot = u % DEPTH;
+      if constexpr (EB == 2) {
+        const int h = u / MT, i = u % MT;
 #pragma unroll
-          for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, fa[h][i]), __builtin_bit_cast(h8, fb[h][j]),
-                                                               acc[i][j], 0, 0, 0);
-    } else if constexpr (EB == 4) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j) {
-            const v4f x = __builtin_bit_cast(v4f, fa[h][i]), y = __builtin_bit_cast(v4f, fb[h][j]);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, y.x, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, y.y, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, y.z, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, y.w, acc[i][j], 0, 0, 0);
-          }
-    } else {
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, ring[slot][0]),
+                                                             __builtin_bit_cast(h8, fb[h][j]), acc[i][j], 0, 0, 0);
+      } else if constexpr (EB == 4) {
+        const int h = u / MT, i = u % MT;
+        const v4f x = __builtin_bit_cast(v4f, ring[slot][0]);
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-          const u32x4 al = fa[0][i], ah = fa[1][i], bl = fb[0][j], bh = fb[1][j];
-          const i32x8 x = {(int)al.x, (int)al.y, (int)al.z, (int)al.w, (int)ah.x, (int)ah.y, (int)ah.z, (int)ah.w};
-          const i32x8 y = {(int)bl.x, (int)bl.y, (int)bl.z, (int)bl.w, (int)bh.x, (int)bh.y, (int)bh.z, (int)bh.w};
-          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(x, y, acc[i][j], 0, 0, 0, 0, 0, 0);
+          const v4f y = __builtin_bit_cast(v4f, fb[h][j]);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, y.x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, y.y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, y.z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, y.w, acc[i][j], 0, 0, 0);
         }
+      } else {
+        const u32x4 al = ring[slot][0], ah = ring[slot][1];
+        const i32x8 x = {(int)al.x, (int)al.y, (int)al.z, (int)al.w, (int)ah.x, (int)ah.y, (int)ah.z, (int)ah.w};
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const u32x4 bl = fb[0][j], bh = fb[1][j];
+          const i32x8 y = {(int)bl.x, (int)bl.y, (int)bl.z, (int)bl.w, (int)bh.x, (int)bh.y, (int)bh.z, (int)bh.w};
+          acc[u][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(x, y, acc[u][j], 0, 0, 0, 0, 0, 0);
+        }
+      }
+      if (u + DEPTH < NA) read_a(u + DEPTH, ring[slot]);
+      if constexpr (NA > DEPTH) __builtin_amdgcn_sched_barrier(0);
     }
   };
   // (Tried: the second wave of each SIMD one phase behind the first -- multiplying the previous
@@ -280,8 +301,7 @@ __global__ __launch_bounds__(TG_WAVES * 64) void gemm_tiled_kernel(
       srcA.stage(s + AHEAD, ldsA(nb));
       srcB.stage(s + AHEAD, ldsB(nb));
     }
-    read_frags(ldsA(cur), ldsB(cur));
-    mma();
+    compute_step(ldsA(cur), ldsB(cur));
     TG_STAMP(3);
     cur = cur + 1 < NBUF ? cur + 1 : 0;
   }
