@@ -90,3 +90,38 @@ def test_batch_f32_fused_overflow_falls_back_exactly(gpu):
         assert_topk_parity(bs[qi], br[qi], [s for s, _ in exp], [i for _, i in exp],
                            oracle.cpu_scores_f64(m, qs[qi]), label=f"f32 overflow q{qi}")
     idx.release()
+
+
+def test_concurrent_mixed_batches_on_one_handle(gpu):
+    """AsyncKB-style concurrency (reference src/svs/kb.py:1184-1190: searches run on executor
+    threads outside the lock) with the batched paths in the mix: single-query GEMV, the
+    16-query streaming kernel with the fused epilogue, the tiled kernel (fused), and the
+    materialised path, all on ONE handle at once.  Every call must return exactly what it
+    returns when it runs alone (per-call contexts: stream, scratch, candidate lists)."""
+    import threading
+    from svs_amd import DeviceIndex
+    m, qs = corpus_and_query("gaussian", 31337, 150000, 512, 48)
+    idx = DeviceIndex(m)
+    jobs = [("single", qs[0:1]), ("b16 fused", qs[0:16]), ("b7 materialised", qs[16:23]),
+            ("b40 tiled fused", qs[8:48]), ("b17", qs[3:20])]
+    k = 64
+    expected = {name: idx.search_batch(q, k) for name, q in jobs}
+    errors = []
+
+    def worker(t):
+        try:
+            for it in range(12):
+                name, q = jobs[(t + it) % len(jobs)]
+                s, r = idx.search_batch(q, k)
+                es, er = expected[name]
+                assert np.array_equal(r, er) and np.array_equal(s, es), f"thread {t} iteration {it}: {name}"
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    idx.release()
+    assert not errors, errors
