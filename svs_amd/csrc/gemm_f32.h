@@ -224,14 +224,23 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void gemm_f32_q16_kernel(
 constexpr int G4_RG = 4;
 constexpr int G4_PF = 2;     // 64-column steps per register buffer (ld % 128 == 0)
 
-template <bool FUSE, int RG = G4_RG, int PF = G4_PF>
-__global__ __launch_bounds__(GEMM_WAVES * 64) void gemm_f32_q16r_kernel(
-    const float* __restrict__ M, const float* __restrict__ Q16, float* __restrict__ scores,
-    int64_t n, int ld, int64_t sstride, int nq, int rows_per_block,
+//
+// EB = bytes per element.  The geometry is in BYTES (a step is 256 B of a row: 64 floats or
+// 128 halves), so the same kernel serves an f16 corpus (EB = 2: queries rounded to half by
+// stage_queries_f16, v_mfma_f32_4x4x4_16b_f16, two per 16-byte load and query group; f32
+// accumulate) -- up to 16 queries over a half corpus stream it at the same ~6.5 TB/s
+// instead of the tiled kernel's 5.0-5.5.  M, Q16: rows of ld16 16-byte units.
+typedef _Float16 h4x __attribute__((ext_vector_type(4)));
+typedef float f32x2q __attribute__((ext_vector_type(2)));
+
+template <bool FUSE, int EB = 4, int RG = G4_RG, int PF = G4_PF>
+__global__ __launch_bounds__(GEMM_WAVES * 64) void gemm_q16r_kernel(
+    const v4f* __restrict__ M, const v4f* __restrict__ Q16, float* __restrict__ scores,
+    int64_t n, int ld16, int64_t sstride, int nq, int rows_per_block,
     uint32_t* __restrict__ fstate = nullptr, int fstate_stride = 0, uint64_t* __restrict__ fcand = nullptr,
     uint32_t fcap = 0, const float* __restrict__ fthr = nullptr, int fthr_stride = 0) {
-  extern __shared__ v4f qlds[];  // [4][ld/64][64], then (FUSE) the parked candidates
-  const int ksteps = ld >> 6;
+  extern __shared__ v4f qlds[];  // [4][ld16/16][64], then (FUSE) the parked candidates
+  const int ksteps = ld16 >> 4;
   uint32_t* lcount = (uint32_t*)(qlds + (size_t)ksteps * 256);
   uint64_t* lkey = (uint64_t*)(lcount + 2);
   uint32_t* lqid = (uint32_t*)(lkey + GEMM_LCAND);
@@ -241,7 +250,7 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void gemm_f32_q16r_kernel(
   for (int e = threadIdx.x; e < ksteps * 256; e += GEMM_WAVES * 64) {
     const int m = e / (ksteps * 64), rem = e - m * ksteps * 64;
     const int s = rem >> 6, l = rem & 63;
-    qlds[e] = *(const v4f*)(Q16 + (int64_t)(4 * m + (l & 3)) * ld + 64 * s + 4 * (l >> 2));
+    qlds[e] = Q16[(int64_t)(4 * m + (l & 3)) * ld16 + 16 * s + (l >> 2)];
   }
   __syncthreads();
 
@@ -254,7 +263,7 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void gemm_f32_q16r_kernel(
     for (int t = 0; t < RG; ++t) {
       int64_t r = row0 + 4 * t + i4;
       r = r < n ? r : n - 1;  // clamp: never read past the matrix
-      p[t] = (const v4f*)(M + r * ld + 4 * b);
+      p[t] = M + r * ld16 + b;
     }
   };
   int64_t row0 = blk0 + wave * TROWS;
@@ -278,13 +287,25 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void gemm_f32_q16r_kernel(
         v4f qf[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) qf[m] = qlds[(m * ksteps + s0 + j) * 64 + lane];
+        if constexpr (EB == 4) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+          for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int t = 0; t < RG; ++t)
+            for (int t = 0; t < RG; ++t)
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
-              acc[t][m] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[t][j][e], qf[m][e], acc[t][m], 0, 0, 0);
+              for (int m = 0; m < 4; ++m)
+                acc[t][m] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[t][j][e], qf[m][e], acc[t][m], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 2; ++e)   // halves 4e .. 4e+3 of the lane's eight
+#pragma unroll
+            for (int t = 0; t < RG; ++t)
+#pragma unroll
+              for (int m = 0; m < 4; ++m) {
+                const f32x2q xa = {a[t][j][2 * e], a[t][j][2 * e + 1]}, xb = {qf[m][2 * e], qf[m][2 * e + 1]};
+                acc[t][m] = __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(h4x, xa), __builtin_bit_cast(h4x, xb), acc[t][m], 0, 0, 0);
+              }
+        }
       }
     };
     int s0 = 0;
@@ -319,22 +340,63 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void gemm_f32_q16r_kernel(
     // acc[t][m][r] in lane (b, j): block b's share of (row 4t + r, query 4m + j).  Sum over b;
     // lane (b, j) then keeps (t, m) = (b >> 2, b & 3): rows 4t .. 4t+3 of query 4m + j.
     f32x4 out = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (RG == 4) {
+      // Reduce-scatter over the four bits of b (lanes l ^ 4, ^ 8, ^ 16, ^ 32): at each level a
+      // lane keeps the half of its values whose (t, m) index matches its own bit, hands the
+      // other half to its partner and adds what it receives -- 60 exchanged values per lane
+      // instead of the 256 of an all-reduce (the epilogue was a quarter of the f32 kernel's
+      // instructions and half of the f16 kernel's).
+      const bool b0 = (b & 1) != 0, b1 = (b & 2) != 0, b2 = (b & 4) != 0, b3 = (b & 8) != 0;
+      f32x4 v8[8], v4[4], v2[2];
 #pragma unroll
-    for (int t = 0; t < RG; ++t)
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        f32x4 v = acc[t][m];
+      for (int s = 0; s < 8; ++s) {
+        const f32x4 lo = acc[(2 * s) >> 2][(2 * s) & 3], hi = acc[(2 * s + 1) >> 2][(2 * s + 1) & 3];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float x = v[r];
-          x += dpp_mov<0x124>(x);   // row_ror:4
-          x += dpp_mov<0x128>(x);   // row_ror:8
-          x += __shfl_xor(x, 16, 64);
-          x += __shfl_xor(x, 32, 64);
-          v[r] = x;
+          const float keep = b0 ? hi[r] : lo[r], send = b0 ? lo[r] : hi[r];
+          // partner l ^ 4: l + 4 for the even quads of a 16-lane row, l - 4 for the odd ones
+          int got = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0x12C /* row_ror:12 */, 0xf, 0x5, false);
+          got = __builtin_amdgcn_update_dpp(got, __builtin_bit_cast(int, send), 0x124 /* row_ror:4 */, 0xf, 0xa, false);
+          v8[s][r] = keep + __builtin_bit_cast(float, got);
         }
-        out = (b == 4 * t + m) ? v : out;
       }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float keep = b1 ? v8[2 * s + 1][r] : v8[2 * s][r], send = b1 ? v8[2 * s][r] : v8[2 * s + 1][r];
+          v4[s][r] = keep + dpp_mov<0x128>(send);   // row_ror:8 == l ^ 8
+        }
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float keep = b2 ? v4[2 * s + 1][r] : v4[2 * s][r], send = b2 ? v4[2 * s][r] : v4[2 * s + 1][r];
+          v2[s][r] = keep + __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, send), 0x401F));   // l ^ 16
+        }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float keep = b3 ? v2[1][r] : v2[0][r], send = b3 ? v2[0][r] : v2[1][r];
+        out[r] = keep + __shfl_xor(send, 32, 64);
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < RG; ++t)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          f32x4 v = acc[t][m];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float x = v[r];
+            x += dpp_mov<0x124>(x);   // row_ror:4
+            x += dpp_mov<0x128>(x);   // row_ror:8
+            x += __shfl_xor(x, 16, 64);
+            x += __shfl_xor(x, 32, 64);
+            v[r] = x;
+          }
+          out = (b == 4 * t + m) ? v : out;
+        }
+    }
     const int query = b < 4 * RG ? 4 * (b & 3) + i4 : GQ;   // lanes past the (t, m) combinations hold nothing
     const int64_t ob = row0 + 4 * (b >> 2);
     if constexpr (FUSE) {

@@ -416,8 +416,14 @@ int launch_scores(const svs_index* idx, Ctx* c, const float* q, float* scores, h
 }
 
 // ---- up to 16 queries per corpus pass (gemm_f32.h) ---------------------------
+size_t elem_bytes(const svs_index* idx) { return idx->dtype == SVS_DTYPE_F32 ? 4 : (idx->dtype == SVS_DTYPE_F16 ? 2 : 1); }
+
 bool batch_kernel_ok(const svs_index* idx) {
-  return idx->dtype == SVS_DTYPE_F32 && idx->ld % 128 == 0 && idx->ld <= 2304 && idx->variant.load() != 7;
+  if (idx->variant.load() == 7) return false;
+  // the query image (16 x row bytes) must fit the LDS beside the fused candidate list
+  if (idx->dtype == SVS_DTYPE_F32) return idx->ld % 128 == 0 && idx->ld <= 2304;
+  if (idx->dtype == SVS_DTYPE_F16) return idx->ld % 128 == 0 && idx->ld <= 4608;
+  return false;
 }
 
 struct FuseLaunch {   // non-null state: fused top-k epilogue, no score matrix
@@ -446,24 +452,26 @@ int stage_queries_f32(const svs_index* idx, Ctx* c, const float* q_dev, int nq, 
   return SVS_OK;
 }
 
-template <class K>
-void launch_q16_kernel(K kernel, const svs_index* idx, const float* q16, int nq_g, int64_t n_rows, float* scores,
-                       int64_t sstride, int rows_per_block, FuseLaunch fl, hipStream_t st) {
+template <class K, class P>
+void launch_q16_kernel(K kernel, const svs_index* idx, const P* rows, const P* q16, int ld_units, size_t row_bytes, int nq_g,
+                       int64_t n_rows, float* scores, int64_t sstride, int rows_per_block, FuseLaunch fl, hipStream_t st) {
   const unsigned blocks = (unsigned)((n_rows + rows_per_block - 1) / rows_per_block);
-  const size_t lds = (size_t)idx->ld * 64 + (fl.state ? GEMM_FUSE_LDS : 0);   // 16 queries x ld floats
+  const size_t lds = row_bytes * 16 + (fl.state ? GEMM_FUSE_LDS : 0);   // 16 queries x row bytes
   hipLaunchKernelGGL(kernel, dim3(blocks), dim3(GEMM_WAVES * 64), lds, st,
-                     (const float*)idx->rows, q16, scores, n_rows, idx->ld, sstride, nq_g, rows_per_block,
+                     rows, q16, scores, n_rows, ld_units, sstride, nq_g, rows_per_block,
                      fl.state, (int)SCR_WORDS, fl.cand, (uint32_t)CAND_CAP, fl.thr, fl.thr_stride);
 }
 
-// q16: 16 staged queries ([16][ld]); rows [0, n_rows)
-int launch_scores_q16(const svs_index* idx, const float* q16, int nq_g, int64_t n_rows, float* scores,
+// q16: 16 staged queries ([16][ld] in the corpus dtype: f32, or halves for an f16 corpus); rows [0, n_rows)
+int launch_scores_q16(const svs_index* idx, const void* q16, int nq_g, int64_t n_rows, float* scores,
                       int64_t sstride, FuseLaunch fl, hipStream_t st) {
   static std::once_flag once;
   std::call_once(once, [] {
     const int lds = 2304 * 64 + GEMM_FUSE_LDS;
-    (void)hipFuncSetAttribute((const void*)gemm_f32_q16r_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute((const void*)gemm_f32_q16r_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)gemm_q16r_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)gemm_q16r_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)gemm_q16r_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)gemm_q16r_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute((const void*)gemm_f32_q16_kernel<false, 2, GEMM_PF, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute((const void*)gemm_f32_q16_kernel<false, 2, GEMM_PF, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   });
@@ -472,12 +480,17 @@ int launch_scores_q16(const svs_index* idx, const float* q16, int nq_g, int64_t 
   // row ranges (the fused path's prefix) take smaller blocks so that every CU gets one.
   int rows_per_block = variant == 4 ? 2048 : (variant == 5 ? 512 : 1024);
   while (rows_per_block > 64 && (n_rows + rows_per_block - 1) / rows_per_block < 512) rows_per_block /= 2;
-  if (variant == 3) {   // A/B: the 16x16x4 kernel (half-line loads)
-    if (fl.state) launch_q16_kernel(gemm_f32_q16_kernel<false, 2, GEMM_PF, true>, idx, q16, nq_g, n_rows, scores, sstride, rows_per_block, fl, st);
-    else launch_q16_kernel(gemm_f32_q16_kernel<false, 2, GEMM_PF, false>, idx, q16, nq_g, n_rows, scores, sstride, rows_per_block, fl, st);
+  const size_t row_bytes = (size_t)idx->ld * elem_bytes(idx);
+  const int ld16 = (int)(row_bytes / 16);
+  if (idx->dtype == SVS_DTYPE_F16) {
+    if (fl.state) launch_q16_kernel(gemm_q16r_kernel<true, 2>, idx, (const v4f*)idx->rows, (const v4f*)q16, ld16, row_bytes, nq_g, n_rows, scores, sstride, rows_per_block, fl, st);
+    else launch_q16_kernel(gemm_q16r_kernel<false, 2>, idx, (const v4f*)idx->rows, (const v4f*)q16, ld16, row_bytes, nq_g, n_rows, scores, sstride, rows_per_block, fl, st);
+  } else if (variant == 3) {   // A/B: the 16x16x4 kernel (half-line loads)
+    if (fl.state) launch_q16_kernel(gemm_f32_q16_kernel<false, 2, GEMM_PF, true>, idx, (const float*)idx->rows, (const float*)q16, idx->ld, row_bytes, nq_g, n_rows, scores, sstride, rows_per_block, fl, st);
+    else launch_q16_kernel(gemm_f32_q16_kernel<false, 2, GEMM_PF, false>, idx, (const float*)idx->rows, (const float*)q16, idx->ld, row_bytes, nq_g, n_rows, scores, sstride, rows_per_block, fl, st);
   } else {
-    if (fl.state) launch_q16_kernel(gemm_f32_q16r_kernel<true>, idx, q16, nq_g, n_rows, scores, sstride, rows_per_block, fl, st);
-    else launch_q16_kernel(gemm_f32_q16r_kernel<false>, idx, q16, nq_g, n_rows, scores, sstride, rows_per_block, fl, st);
+    if (fl.state) launch_q16_kernel(gemm_q16r_kernel<true, 4>, idx, (const v4f*)idx->rows, (const v4f*)q16, ld16, row_bytes, nq_g, n_rows, scores, sstride, rows_per_block, fl, st);
+    else launch_q16_kernel(gemm_q16r_kernel<false, 4>, idx, (const v4f*)idx->rows, (const v4f*)q16, ld16, row_bytes, nq_g, n_rows, scores, sstride, rows_per_block, fl, st);
   }
   return SVS_OK;
 }
@@ -596,7 +609,9 @@ int run_select(svs_index* idx, Ctx* c, const float* scores, int64_t n_eff, int64
 // candidates per query survive, so the prefix grows with n (n/64 -> ~64 k survivors)
 // Materialised scores of nq queries: scores[q][sstride] (the non-fused score stage).
 bool uses_q16(const svs_index* idx, int nq) {
-  return nq >= 2 && batch_kernel_ok(idx) && (nq <= GQ || idx->variant.load() == 5 || !tiled_ok(idx));
+  if (nq < 2 || !batch_kernel_ok(idx)) return false;
+  if (idx->dtype == SVS_DTYPE_F16) return nq <= GQ && idx->variant.load() != 5;   // (variant 5: tiled kernel, A/B)
+  return nq <= GQ || idx->variant.load() == 5 || !tiled_ok(idx);
 }
 
 // rows [0, n_rows); fl.state != null: fused epilogue (batched kernels only); restage == false
@@ -607,13 +622,19 @@ int launch_scores_any(svs_index* idx, Ctx* c, const float* q_dev, int64_t n_rows
   // f32: up to 16 queries -> the 16-query streaming kernel; more -> the tiled kernel at 32
   // queries per pass (bound by the f32 MFMA rate)
   if (uses_q16(idx, nq)) {
+    const bool f16 = idx->dtype == SVS_DTYPE_F16;
     if (restage) {
-      const float* qs = nullptr;
-      if ((rc = stage_queries_f32(idx, c, q_dev, nq, GQ, &qs, st)) != SVS_OK) return rc;
-      c->q_f32 = qs;
+      if (f16) {
+        if ((rc = stage_queries_f16(idx, c, q_dev, nq, (nq + GQ - 1) / GQ * GQ, st)) != SVS_OK) return rc;
+      } else {
+        const float* qs = nullptr;
+        if ((rc = stage_queries_f32(idx, c, q_dev, nq, GQ, &qs, st)) != SVS_OK) return rc;
+        c->q_f32 = qs;
+      }
     }
     for (int q0 = 0; q0 < nq; q0 += GQ) {
-      rc = launch_scores_q16(idx, c->q_f32 + (size_t)q0 * idx->ld, std::min(GQ, nq - q0), n_rows,
+      const void* qg = f16 ? (const void*)((const _Float16*)c->qh + (size_t)q0 * idx->ld) : (const void*)(c->q_f32 + (size_t)q0 * idx->ld);
+      rc = launch_scores_q16(idx, qg, std::min(GQ, nq - q0), n_rows,
                              scores ? scores + (size_t)q0 * sstride : nullptr, sstride, fl.at(q0), st);
       if (rc != SVS_OK) return rc;
     }
@@ -645,7 +666,7 @@ int enqueue_search(svs_index* idx, Ctx* c, const float* q_dev, int nq, int k, in
   // pass costs ~60 us whatever the batch: measured break-even is 16 queries for f32
   // (13.2 k vs 12.7 k queries/s at 16, 26.9 k vs 24.6 k at 256; 8 queries: 6.4 k vs 6.5 k).
   const bool batched = uses_q16(idx, nq) || (nq >= 2 && tiled_ok(idx));
-  const bool fused = allow_fused && path_a && batched && nq >= (idx->dtype == SVS_DTYPE_F32 ? 16 : 64) &&
+  const bool fused = allow_fused && path_a && batched && nq >= ((idx->dtype == SVS_DTYPE_F32 || uses_q16(idx, nq)) ? 16 : 64) &&
                      n >= 8 * FUSE_PREFIX_MIN && (int64_t)n < ((int64_t)1 << 32) &&
                      count <= 256 && idx->dead_list.empty() && idx->variant.load() != 6;
   const int64_t n_mat = fused ? fuse_prefix_rows(n) : n;     // rows of the materialised score matrix
@@ -771,7 +792,6 @@ hipError_t upload_host_rows(svs_index* idx, const float* host_rows, int64_t nrow
   return e;
 }
 
-size_t elem_bytes(const svs_index* idx) { return idx->dtype == SVS_DTYPE_F32 ? 4 : (idx->dtype == SVS_DTYPE_F16 ? 2 : 1); }
 
 // Row stride in elements.  Rows are always 16-byte aligned (4 floats / 8 halves /
 // 16 fp8).  When the dimension is not a whole number of 1 KiB wave loads but padding it
