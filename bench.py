@@ -269,7 +269,9 @@ def main():
             gb.manual_seed(args.seed + 999 + B)
             qb = torch.randn((B, d), device=dev, dtype=torch.float32, generator=gb)
             qb = (qb / qb.norm(dim=1, keepdim=True)).cpu().numpy()
-            for _ in range(3):
+            # (the first ~10 ms after a change of kernel mix run at a settling clock: the 16-query
+            # kernel takes 1.0-1.3 ms during it and 1.0 after, profiles/r1_b16_kernel_stats.csv)
+            for _ in range(max(3, min(15, 256 // B))):
                 idx.search_batch(qb, k)
             idx.set_timing(True)
             reps = max(3, min(30, 512 // B))
