@@ -1,5 +1,5 @@
-// Score stage, up to 16 queries per corpus pass, f32 corpus, exact f32 math
-// (batches of more than 16 queries take gemm_tiled.h with EB = 4, 32 per pass):
+// Score stage, up to 16 queries per corpus pass: f32 corpus with exact f32 math, or an
+// f16 corpus with f32 accumulation (batches of more than 16 queries take gemm_tiled.h):
 //     scores[j][i] = sum_d M[i,d] * Q[j,d]        j < 16
 // The reference has no batched entry (a batch is a loop of np.dot calls,
 // src/svs/kb.py:1623); this kernel amortises ONE read of the corpus over 16
@@ -7,7 +7,7 @@
 // (BASELINE.json north_star) while staying HBM-bound: 16 x 2 flop per 4 corpus
 // bytes = 8 flop/B, far below the f32 ridge.
 //
-// Two kernels compute it.  gemm_f32_q16r_kernel (second half of this file, 4x4x1 MFMA,
+// Two kernels compute it.  gemm_q16r_kernel (second half of this file, 4x4x1 / 4x4x4 MFMA,
 // whole-line loads) is the product path; gemm_f32_q16_kernel (16x16x4 MFMA, half-line
 // loads) is the first design, kept behind svs_index_set_variant(3) as the measured
 // alternative (1.21 vs 1.10 ms per 16 queries at 1M x 1536).

@@ -31,7 +31,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "gemm_f32.h"
+#include "gemm_q16.h"
 #include "fp8.h"
 #include "gemv_f16.h"
 #include "keys.h"

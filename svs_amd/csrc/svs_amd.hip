@@ -19,7 +19,7 @@
 
 #include "fp8.h"
 #include "gemm_tiled.h"
-#include "gemm_f32.h"
+#include "gemm_q16.h"
 #include "gemv_f16.h"
 #include "gemv_f32.h"
 #include "select.h"
@@ -413,7 +413,7 @@ int launch_scores(const svs_index* idx, Ctx* c, const float* q, float* scores, h
   return SVS_OK;
 }
 
-// ---- up to 16 queries per corpus pass (gemm_f32.h) ---------------------------
+// ---- up to 16 queries per corpus pass (gemm_q16.h) ---------------------------
 size_t elem_bytes(const svs_index* idx) { return idx->dtype == SVS_DTYPE_F32 ? 4 : (idx->dtype == SVS_DTYPE_F16 ? 2 : 1); }
 
 bool batch_kernel_ok(const svs_index* idx) {

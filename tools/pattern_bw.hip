@@ -8,7 +8,7 @@
 #include <cstdlib>
 #include <vector>
 #include "../svs_amd/csrc/gemv_f32.h"
-#include "../svs_amd/csrc/gemm_f32.h"
+#include "../svs_amd/csrc/gemm_q16.h"
 using namespace svs;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
