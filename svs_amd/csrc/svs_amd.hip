@@ -63,6 +63,7 @@ struct Ctx {
   float* q8s = nullptr;         size_t q8s_cap = 0;      // query scales
   const float* q_f32 = nullptr;                          // staged f32 queries (q16 or the caller's buffer)
   float* pref_s = nullptr;      size_t pref_s_cap = 0;   // fused GEMM: top-k of the prefix rows (thresholds)
+  int64_t* pref_r = nullptr;    size_t pref_r_cap = 0;
   float* scores = nullptr;      size_t scores_cap = 0;   // floats
   uint32_t* hist = nullptr;     size_t hist_cap = 0;     // queries
   uint64_t* cand = nullptr;                               // counters live behind hist
@@ -121,6 +122,7 @@ void ctx_destroy(Ctx* c) {
   (void)hipFree(c->q8f);
   (void)hipFree(c->q8s);
   (void)hipFree(c->pref_s);
+  (void)hipFree(c->pref_r);
   (void)hipFree(c->scores);
   (void)hipFree(c->hist);
   (void)hipFree(c->cand);
@@ -692,12 +694,20 @@ int enqueue_search(svs_index* idx, Ctx* c, const float* q_dev, int nq, int k, in
     HIP_TRY(hipEventRecord(ev.e0, st));
   }
   if (fused) {
-    // 1. thresholds: exact k-th best of the first FUSE_PREFIX_ROWS rows, per query
-    if ((rc = grow_dev(&c->pref_s, &c->pref_s_cap, (size_t)nq)) != SVS_OK) return rc;
+    // 1. thresholds: exact k-th best of the first FUSE_PREFIX_ROWS rows, per query.  Many queries
+    // over a short prefix: one k-th-value kernel (47 vs 62 us at 1024 x 16,384); otherwise the
+    // ordinary three-launch top-k, whose kernels spread one query over many workgroups
+    // (16 queries: 20 vs 33 us; 256 x 156,250 rows: 119 vs 284 us).
+    const bool kth = nq >= 256 && n_mat <= 32768;
+    if ((rc = grow_dev(&c->pref_s, &c->pref_s_cap, (size_t)nq * (kth ? 1 : count))) != SVS_OK) return rc;
+    if (!kth && (rc = grow_dev(&c->pref_r, &c->pref_r_cap, (size_t)nq * count)) != SVS_OK) return rc;
     if ((rc = launch_scores_any(idx, c, q_dev, n_mat, nq, c->scores, sstride, FuseLaunch{}, st)) != SVS_OK) return rc;
-    hipLaunchKernelGGL(prefix_kth_kernel, dim3(nq), dim3(FINAL_THREADS), 0, st, (const float*)c->scores, n_mat, sstride, count, c->pref_s);
+    if (kth)
+      hipLaunchKernelGGL(prefix_kth_kernel, dim3(nq), dim3(FINAL_THREADS), 0, st, (const float*)c->scores, n_mat, sstride, count, c->pref_s);
+    else if ((rc = run_select(idx, c, c->scores, n_mat, sstride, nq, count, count, c->pref_s, c->pref_r, st, idx->row_offset)) != SVS_OK)
+      return rc;
     // 2. the whole corpus, keeping only scores >= threshold
-    FuseLaunch fl{c->hist, c->cand, c->pref_s, 1};
+    FuseLaunch fl{c->hist, c->cand, kth ? c->pref_s : c->pref_s + (count - 1), kth ? 1 : count};
     if ((rc = launch_scores_any(idx, c, q_dev, n, nq, nullptr, 0, fl, st, false)) != SVS_OK) return rc;
     if (timed) HIP_TRY(hipEventRecord(ev.e1, st));
     hipLaunchKernelGGL(select_final_kernel, dim3(nq), dim3(FINAL_THREADS), 0, st, (const float*)nullptr, n, (int64_t)0, k, count, 3,
