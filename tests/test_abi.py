@@ -50,3 +50,29 @@ def test_product_code_never_imports_the_oracle():
                 with open(os.path.join(dp, fn)) as f:
                     src = f.read()
                 assert "import oracle" not in src and "from oracle" not in src and "svs_oracle" not in src, fn
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/svs_amd.h is the drop-in boundary: it must compile as C99 (no C++, no torch or
+    HIP types in the signatures) and a C program must link against the library with it."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "abi.c"
+    src.write_text(
+        '#include "svs_amd.h"\n'
+        '#include <stdio.h>\n'
+        'int main(void) {\n'
+        '  svs_index_info_t info; svs_timing_t t; (void)info; (void)t;\n'
+        '  printf("%s\\n", svs_version());\n'
+        '  return svs_index_release((svs_index*)0) == SVS_OK ? 1 : 0;   /* null handle: an error, not a crash */\n'
+        '}\n')
+    lib_dir = os.path.join(root, "svs_amd", "lib")
+    exe = tmp_path / "abi"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
+                    str(src), "-o", str(exe), "-L", lib_dir, "-lsvs_amd", "-Wl,-rpath," + lib_dir,
+                    "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and "svs_amd" in out.stdout, (out.returncode, out.stdout, out.stderr)
