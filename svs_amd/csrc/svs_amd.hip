@@ -422,7 +422,7 @@ bool batch_kernel_ok(const svs_index* idx) {
   if (idx->variant.load() == 7) return false;
   // the query image (16 x row bytes) must fit the LDS beside the fused candidate list
   if (idx->dtype == SVS_DTYPE_F32) return idx->ld % 128 == 0 && idx->ld <= 2304;
-  if (idx->dtype == SVS_DTYPE_F16) return idx->ld % 128 == 0 && idx->ld <= 4608;
+  if (idx->dtype == SVS_DTYPE_F16) return idx->ld % 256 == 0 && idx->ld <= 4608;   // whole pairs of 256-byte steps
   return false;
 }
 

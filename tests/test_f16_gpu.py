@@ -112,3 +112,25 @@ def test_f16_fused_overflow_falls_back_exactly(gpu):
         assert_topk_parity(bs[qi], br[qi], [s for s, _ in exp], [i for _, i in exp],
                            oracle.cpu_scores_f64(md, qd), label=f"overflow q{qi}")
     idx.release()
+
+
+@pytest.mark.parametrize("n,d,nq,k", [(20000, 1536, 2, 100), (20000, 1536, 16, 100), (15000, 1280, 9, 50),
+                                      (15000, 1664, 12, 50), (15000, 1408, 16, 50), (6000, 4608, 5, 20),
+                                      (140000, 512, 16, 100), (133000, 1024, 16, 256)])
+def test_f16_small_batches_streaming_kernel(gpu, n, d, nq, k):
+    """Up to 16 queries over an f16 corpus whose rows are whole pairs of 256-byte steps take the
+    streaming kernel (v_mfma_f32_4x4x4_16b_f16, whole-line loads); other dimensions (1664 and
+    1408 halves here) the tiled kernel; 16 queries over >= 131,072 rows run it with the fused
+    top-k epilogue.  All against numpy on the half-rounded corpus and queries."""
+    from svs_amd import DeviceIndex
+    m, qs = corpus_and_query("gaussian", 8100 + n + d + nq, n, d, nq)
+    idx = DeviceIndex(m, dtype="f16")
+    md = _deq(m)
+    bs, br = idx.search_batch(qs, k)
+    assert bs.shape == (nq, k)
+    for qi in range(nq):
+        qd = _deq(qs[qi])
+        exp = oracle.cpu_search(md, qd, k)
+        assert_topk_parity(bs[qi], br[qi], [s for s, _ in exp], [i for _, i in exp],
+                           oracle.cpu_scores_f64(md, qd), label=f"f16 stream {n}x{d} nq={nq} q{qi}")
+    idx.release()
