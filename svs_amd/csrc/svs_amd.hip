@@ -20,6 +20,7 @@
 #include "fp8.h"
 #include "gemm_tiled.h"
 #include "gemm_q16.h"
+#include "gemv_unrolled.h"
 #include "gemv_f16.h"
 #include "gemv_f32.h"
 #include "select.h"
@@ -318,6 +319,36 @@ void launch_gemv_fp8(const svs_index* idx, Ctx* c, float* scores, hipStream_t st
                      (const v4f*)c->q8f, c->q8s, scores, idx->n, idx->ld / 16);
 }
 
+// Rows that are not whole 1 KiB wave loads (gemv_unrolled.h); false: longer than 16 KiB
+template <class Dot>
+bool launch_unrolled(const svs_index* idx, const void* q_staged, int ld16, float* scores, hipStream_t st, Dot dot) {
+  const u32x4* M = (const u32x4*)idx->rows;
+  const u32x4* q = (const u32x4*)q_staged;
+#define SVS_UNROLLED(T, NC, U)                                                                                   \
+  do {                                                                                                           \
+    const int64_t groups = (idx->n + (64 / (T)) * (U) - 1) / ((64 / (T)) * (U));                                   \
+    const int64_t blocks = (groups + UNR_WPB - 1) / UNR_WPB;                                                       \
+    hipLaunchKernelGGL((gemv_unrolled_kernel<T, NC, U, Dot>), dim3((unsigned)blocks), dim3(UNR_WPB * 64), 0, st, M, q, scores, idx->n, ld16, dot); \
+    return true;                                                                                                 \
+  } while (0)
+  if (ld16 <= 1) SVS_UNROLLED(1, 1, 8);
+  if (ld16 <= 2) SVS_UNROLLED(2, 1, 8);
+  if (ld16 <= 4) SVS_UNROLLED(4, 1, 8);
+  if (ld16 <= 8) SVS_UNROLLED(8, 1, 8);
+  if (ld16 <= 16) SVS_UNROLLED(16, 1, 8);
+  if (ld16 <= 32) SVS_UNROLLED(32, 1, 8);
+  if (ld16 <= 64) SVS_UNROLLED(64, 1, 8);
+  if (ld16 <= 128) SVS_UNROLLED(64, 2, 4);
+  if (ld16 <= 192) SVS_UNROLLED(64, 3, 2);
+  if (ld16 <= 256) SVS_UNROLLED(64, 4, 2);
+  if (ld16 <= 384) SVS_UNROLLED(64, 6, 1);
+  if (ld16 <= 512) SVS_UNROLLED(64, 8, 1);
+  if (ld16 <= 768) SVS_UNROLLED(64, 12, 1);
+  if (ld16 <= 1024) SVS_UNROLLED(64, 16, 1);
+#undef SVS_UNROLLED
+  return false;
+}
+
 // q: device, d floats (unpadded); scores: device, n floats
 int launch_scores(const svs_index* idx, Ctx* c, const float* q, float* scores, hipStream_t st) {
   const int variant = idx->variant.load();
@@ -346,6 +377,7 @@ int launch_scores(const svs_index* idx, Ctx* c, const float* q, float* scores, h
     }
 #undef SVS_FP8_HOT
     const int ld16 = idx->ld / 16;
+    if (variant != 4 && launch_unrolled(idx, c->q8, ld16, scores, st, DotFp8{idx->row_scales, c->q8s})) return SVS_OK;
     if (ld16 <= 1) launch_gemv_fp8<1>(idx, c, scores, st);
     else if (ld16 <= 2) launch_gemv_fp8<2>(idx, c, scores, st);
     else if (ld16 <= 4) launch_gemv_fp8<4>(idx, c, scores, st);
@@ -376,6 +408,7 @@ int launch_scores(const svs_index* idx, Ctx* c, const float* q, float* scores, h
     int rc = stage_queries_f16(idx, c, q, 1, 1, st);
     if (rc != SVS_OK) return rc;
     const int ld8 = idx->ld / 8;
+    if (variant != 4 && launch_unrolled(idx, c->qh, ld8, scores, st, DotF16{})) return SVS_OK;
     if (ld8 <= 1) launch_generic_f16<1>(idx, c->qh, scores, st);
     else if (ld8 <= 2) launch_generic_f16<2>(idx, c->qh, scores, st);
     else if (ld8 <= 4) launch_generic_f16<4>(idx, c->qh, scores, st);
@@ -405,6 +438,19 @@ int launch_scores(const svs_index* idx, Ctx* c, const float* q, float* scores, h
     }
   }
   const int ld4 = idx->ld / 4;
+  if (variant != 4 && ld4 <= 1024) {
+    // rows of up to 16 KiB that are not whole wave loads (gemv_unrolled.h): the query is read in
+    // 16-byte chunks of the padded row, so it is padded (and aligned) the same way
+    const float* qq = q;
+    if (idx->ld != idx->d || !q_aligned) {
+      int rc = grow_dev(&c->q16, &c->q16_cap, (size_t)GQ * idx->ld);
+      if (rc != SVS_OK) return rc;
+      HIP_TRY(hipMemsetAsync(c->q16, 0, (size_t)idx->ld * sizeof(float), st));
+      HIP_TRY(hipMemcpyAsync(c->q16, q, (size_t)idx->d * sizeof(float), hipMemcpyDeviceToDevice, st));
+      qq = c->q16;
+    }
+    if (launch_unrolled(idx, qq, ld4, scores, st, DotF32{})) return SVS_OK;
+  }
   if (ld4 <= 1) launch_generic<1>(idx, q, scores, st);
   else if (ld4 <= 2) launch_generic<2>(idx, q, scores, st);
   else if (ld4 <= 4) launch_generic<4>(idx, q, scores, st);
@@ -800,19 +846,22 @@ hipError_t upload_host_rows(svs_index* idx, const float* host_rows, int64_t nrow
 }
 
 
-// Row stride in elements.  Rows are always 16-byte aligned (4 floats / 8 halves /
-// 16 fp8).  When the dimension is not a whole number of 1 KiB wave loads but padding it
-// up costs at most a third more bytes, the row is padded to that geometry (zero
-// columns): the streaming kernels then run at ~7 TB/s instead of the generic
-// kernel's ~3.5 (d = 1000 -> 1024: 2.4 % more bytes, twice the speed).
+// Row stride in elements.  Rows are always 16-byte aligned (4 floats / 8 halves / 16 fp8).
+//  1. A whole number of 1 KiB wave loads when that costs at most an eighth more bytes (zero
+//     columns): the exact-geometry streaming kernels, ~7 TB/s (d = 1000 -> 1024: +2.4 %).
+//  2. Otherwise whole 128-byte lines per row, again for at most an eighth more: rows then never
+//     share a cache line (the streams are nontemporal), the tiled kernels' 128-byte k-steps
+//     apply, and gemv_unrolled.h streams such rows at 6.6-7.1 TB/s (d = 384 f16: 768-byte rows;
+//     the earlier rule padded them to 1 KiB, +33 % bytes).
+//  3. Otherwise tight.
 int choose_ld(int d, int dtype) {
-  const int align = dtype == SVS_DTYPE_F32 ? 4 : (dtype == SVS_DTYPE_F16 ? 8 : 16);
-  const int wave = 64 * align;                        // elements per 1 KiB wave load
+  const int align = dtype == SVS_DTYPE_F32 ? 4 : (dtype == SVS_DTYPE_F16 ? 8 : 16);   // elements per 16 bytes
   const int tight = (d + align - 1) / align * align;
-  if (d <= 0 || d % wave == 0) return tight;
-  if (dtype == SVS_DTYPE_FP8 && d % 512 == 0) return tight;   // served by the 8-byte-per-lane kernel
-  const int padded = (d + wave - 1) / wave * wave;
-  if (padded <= 16 * wave && (int64_t)padded * 3 <= (int64_t)d * 4) return padded;
+  if (d <= 0) return tight;
+  const int wave = 64 * align, line = 8 * align;
+  const int waved = (d + wave - 1) / wave * wave, lined = (d + line - 1) / line * line;
+  if ((int64_t)waved * 8 <= (int64_t)tight * 9) return waved;
+  if ((int64_t)lined * 8 <= (int64_t)tight * 9) return lined;
   return tight;
 }
 
