@@ -17,19 +17,22 @@
 namespace svs {
 
 // A Dot functor: prep() turns the lane's 16-byte query chunk into whatever the inner product
-// wants (done once per wave), dot() multiplies one 16-byte row chunk, finish() scales.
+// wants (done once per wave), dot() multiplies one 16-byte row chunk, pre() fetches what
+// finish() needs about the row (its scale) together with the row, finish() applies it.
 struct DotF32 {   // 4 floats per chunk, plain FMAs: the reference's arithmetic
   typedef v4f Q;
   __device__ __forceinline__ Q prep(u32x4 q) const { return __builtin_bit_cast(v4f, q); }
   __device__ __forceinline__ float dot(u32x4 a, const Q& q, float acc) const { return dot4(__builtin_bit_cast(v4f, a), q, acc); }
-  __device__ __forceinline__ float finish(float v, int64_t) const { return v; }
+  __device__ __forceinline__ float pre(int64_t) const { return 1.f; }
+  __device__ __forceinline__ float finish(float v, float) const { return v; }
 };
 
 struct DotF16 {   // rows and query in halves, f32 accumulate (v_dot2_f32_f16)
   typedef u32x4 Q;
   __device__ __forceinline__ Q prep(u32x4 q) const { return q; }
   __device__ __forceinline__ float dot(u32x4 a, const Q& q, float acc) const { return dot8(a, q, acc); }
-  __device__ __forceinline__ float finish(float v, int64_t) const { return v; }
+  __device__ __forceinline__ float pre(int64_t) const { return 1.f; }
+  __device__ __forceinline__ float finish(float v, float) const { return v; }
 };
 
 struct DotFp8 {   // rows in e4m3 (16 per chunk); the query chunk is widened to f32 once; scales at the end
@@ -60,7 +63,8 @@ struct DotFp8 {   // rows in e4m3 (16 per chunk); the query chunk is widened to 
     }
     return acc;
   }
-  __device__ __forceinline__ float finish(float v, int64_t row) const { return v * row_scales[row] * q_scale[0]; }
+  __device__ __forceinline__ float pre(int64_t row) const { return row_scales[row] * q_scale[0]; }   // requested with the row itself
+  __device__ __forceinline__ float finish(float v, float scale) const { return v * scale; }
 };
 
 // Sum over the T lanes that share a row, result in (at least) the segment's first lane.
@@ -103,6 +107,7 @@ __global__ __launch_bounds__(UNR_WPB * 64) void gemv_unrolled_kernel(
   }
   {
     u32x4 a[U][NC];
+    float extra[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       int64_t row = base + u * RPW + rsub;
@@ -110,6 +115,7 @@ __global__ __launch_bounds__(UNR_WPB * 64) void gemv_unrolled_kernel(
       const u32x4* p = M + row * ld16;
 #pragma unroll
       for (int c = 0; c < NC; ++c) a[u][c] = __builtin_nontemporal_load(p + col[c]);
+      extra[u] = dot.pre(row);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -118,7 +124,7 @@ __global__ __launch_bounds__(UNR_WPB * 64) void gemv_unrolled_kernel(
       for (int c = 0; c < NC; ++c) acc = dot.dot(a[u][c], qv[c], acc);
       acc = seg_sum<T>(acc);
       const int64_t row = base + u * RPW + rsub;
-      if (sub == 0 && row < n) scores[row] = dot.finish(acc, row);
+      if (sub == 0 && row < n) scores[row] = dot.finish(acc, extra[u]);
     }
   }
 }
