@@ -709,10 +709,10 @@ int enqueue_search(svs_index* idx, Ctx* c, const float* q_dev, int nq, int k, in
   const bool path_a = k > 0 && n > SORT_CAP && count <= SEL_KMAX;
   // Fused top-k epilogue (no score matrix) for the batched kernels; a query whose
   // candidate list overflows comes back marked and is re-run by the caller.  The prefix
-  // pass costs ~60 us whatever the batch: measured break-even is 16 queries for f32
-  // (13.2 k vs 12.7 k queries/s at 16, 26.9 k vs 24.6 k at 256; 8 queries: 6.4 k vs 6.5 k).
+  // pass costs ~60 us whatever the batch: measured break-even is 16 queries (f32: 13.2 k vs
+  // 12.7 k queries/s at 16, 6.4 k vs 6.5 k at 8; f16 at 32: 49 k vs 41 k; fp8 at 32: 77 k vs 64 k).
   const bool batched = uses_q16(idx, nq) || (nq >= 2 && tiled_ok(idx));
-  const bool fused = allow_fused && path_a && batched && nq >= ((idx->dtype == SVS_DTYPE_F32 || uses_q16(idx, nq)) ? 16 : 64) &&
+  const bool fused = allow_fused && path_a && batched && nq >= 16 &&
                      n >= 8 * FUSE_PREFIX_MIN && (int64_t)n < ((int64_t)1 << 32) &&
                      count <= 256 && idx->dead_list.empty() && idx->variant.load() != 6;
   const int64_t n_mat = fused ? fuse_prefix_rows(n) : n;     // rows of the materialised score matrix

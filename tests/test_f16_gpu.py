@@ -67,9 +67,9 @@ def test_f16_recall_vs_f32(gpu):
 
 
 @pytest.mark.parametrize("n,d,nq,k", [(140000, 768, 64, 100), (131072, 256, 100, 10), (150001, 512, 300, 100),
-                                      (40000, 1536, 64, 100)])
+                                      (40000, 1536, 64, 100), (140000, 768, 17, 100), (135000, 1536, 33, 50)])
 def test_f16_large_batch_fused_topk(gpu, n, d, nq, k):
-    """nq >= 64 over >= 131,072 rows takes the tiled MFMA GEMM with the fused top-k
+    """nq >= 16 over >= 131,072 rows takes the batched kernels with the fused top-k
     epilogue (the score matrix is never materialised; thresholds come from a
     16,384-row prefix); smaller corpora take the materialised path."""
     from svs_amd import DeviceIndex

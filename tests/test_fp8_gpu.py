@@ -46,10 +46,11 @@ def test_fp8_single_query(gpu, n, d, k):
 
 
 @pytest.mark.parametrize("n,d,nq,k", [(20000, 3072, 32, 100), (20000, 1536, 33, 100), (9000, 3072, 256, 50),
-                                      (5000, 128, 7, 100), (140000, 768, 64, 100)])
+                                      (5000, 128, 7, 100), (140000, 768, 64, 100), (135000, 1536, 17, 100),
+                                      (140000, 3072, 40, 50)])
 def test_fp8_batch_mfma(gpu, n, d, nq, k):
-    """Batched path: e4m3 operands on v_mfma_f32_16x16x32_fp8_fp8 (the last case also
-    takes the fused top-k epilogue)."""
+    """Batched path: e4m3 operands on v_mfma_f32_16x16x128_f8f6f4 (the cases with >= 16 queries
+    over >= 131,072 rows also take the fused top-k epilogue)."""
     from svs_amd import DeviceIndex
     m, qs = corpus_and_query("gaussian", 600 + n + nq, n, d, nq)
     idx = DeviceIndex(m, dtype="fp8")
