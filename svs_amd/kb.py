@@ -213,11 +213,14 @@ class KB:
     src/svs/kb.py:1407-1640."""
 
     def __init__(self, local_path: str, embedding_func: Optional[EmbeddingFunc] = None,
-                 device: int = 0, index_factory: Callable[..., Any] = DeviceIndex):
+                 device: int = 0, index_factory: Callable[..., Any] = DeviceIndex, dtype: str = "f32"):
         if embedding_func is None:
             raise RuntimeError("No embedding function. You must pass the embedding function you want to use.")
         self.embedding_func = embedding_func
         self.db: Optional[_Store] = _Store(local_path)
+        if dtype != "f32":   # storage dtype of the HBM copy ("f16", "fp8"); f32 is the reference's arithmetic
+            import functools
+            index_factory = functools.partial(index_factory, dtype=dtype)
         self.embeddings_matrix = DeviceEmbeddingsMatrix(device=device, builder=_build_from_store,
                                                         index_factory=index_factory, keep_host_matrix=False)
         self._loop = asyncio.new_event_loop()
@@ -373,13 +376,16 @@ class AsyncKB:
     concurrently -- the C ABI is re-entrant for exactly this."""
 
     def __init__(self, local_path: str, embedding_func: Optional[EmbeddingFunc] = None,
-                 device: int = 0, index_factory: Callable[..., Any] = DeviceIndex):
+                 device: int = 0, index_factory: Callable[..., Any] = DeviceIndex, dtype: str = "f32"):
         if embedding_func is None:
             raise RuntimeError("No embedding function. You must pass the embedding function you want to use.")
         self.embedding_func = embedding_func
         self._path = local_path
         self.db: Optional[_Store] = None
         self._lock: Optional[asyncio.Lock] = None
+        if dtype != "f32":   # storage dtype of the HBM copy ("f16", "fp8"); f32 is the reference's arithmetic
+            import functools
+            index_factory = functools.partial(index_factory, dtype=dtype)
         self.embeddings_matrix = DeviceEmbeddingsMatrix(device=device, builder=_build_from_store,
                                                         index_factory=index_factory, keep_host_matrix=False)
 

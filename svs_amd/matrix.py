@@ -325,15 +325,18 @@ class DeviceMatrixView:
 
 
 def attach(kb, device: int = 0, keep_host_matrix: bool = True, index_factory: Callable[..., Any] = DeviceIndex,
-           devices: Optional[List[int]] = None):
+           devices: Optional[List[int]] = None, dtype: str = "f32"):
     """Swap a reference ``svs.KB`` / ``svs.AsyncKB`` instance's matrix cache for
     the device-backed one.  No reference source line changes; ``retrieve()``
     keeps its exact surface.  ``devices=[0, 1, ...]`` row-shards the corpus over
-    several GPUs of this process (``svs_amd.multi.MultiDeviceIndex``)."""
+    several GPUs of this process (``svs_amd.multi.MultiDeviceIndex``); ``dtype``
+    ("f32" = the reference's arithmetic, "f16", "fp8") is how the corpus is stored in HBM."""
+    import functools
     if devices is not None and len(devices) > 1:
-        import functools
         from .multi import MultiDeviceIndex
-        index_factory = functools.partial(MultiDeviceIndex, devices=list(devices))
+        index_factory = functools.partial(MultiDeviceIndex, devices=list(devices), dtype=dtype)
+    elif dtype != "f32":
+        index_factory = functools.partial(index_factory, dtype=dtype)
     old = kb.embeddings_matrix
     new = DeviceEmbeddingsMatrix(device=device, keep_host_matrix=keep_host_matrix,
                                  index_factory=index_factory, view=True)

@@ -64,3 +64,30 @@ def test_async_concurrent_retrieves_and_invalidate(gpu, tmp_path):
         await kb.close()
 
     asyncio.run(run())
+
+
+@pytest.mark.parametrize("dtype", ["f16", "fp8"])
+def test_kb_with_a_reduced_precision_corpus(gpu, tmp_path, dtype):
+    """KB(..., dtype=...) / attach(kb, dtype=...): same retrieve() surface, corpus stored as
+    halves or e4m3 in HBM.  Every document must still find itself first."""
+    import svs_amd
+    rng = np.random.default_rng(3)
+    vecs = rng.standard_normal((500, 384))
+    vecs /= np.linalg.norm(vecs, axis=1, keepdims=True)
+    table = {f"doc {i}": [float(x) for x in vecs[i]] for i in range(500)}
+
+    async def ef(texts):
+        return [table[t] for t in texts]
+
+    kb = svs_amd.KB(str(tmp_path / f"{dtype}.sqlite"), ef, dtype=dtype)
+    with kb.bulk_add_docs() as add_doc:
+        for i in range(500):
+            add_doc(f"doc {i}")
+    for i in (0, 17, 499):
+        docs = kb.retrieve(f"doc {i}", 5)
+        assert docs[0]["doc"]["text"] == f"doc {i}" and abs(docs[0]["score"] - 1.0) < (2e-3 if dtype == "f16" else 3e-2)
+        assert len(docs) == 5 and all(docs[j]["score"] >= docs[j + 1]["score"] for j in range(4))
+    assert kb.embeddings_matrix.index.dtype == dtype
+    many = kb.retrieve_many([f"doc {i}" for i in range(40)], 3)
+    assert [r[0]["doc"]["text"] for r in many] == [f"doc {i}" for i in range(40)]
+    kb.close()
