@@ -307,6 +307,17 @@ __global__ __launch_bounds__(TG_WAVES * 64) void gemm_tiled_kernel(
   }
 
   TG_STAMP_BLOCK(2);
+  // fp8: the lane's MT * 4 row scales, fetched once (they are the same for every query tile)
+  f32x4_t rs[EB == 1 ? MT : 1];
+  if constexpr (EB == 1) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int64_t ob = row0 + wm * TM + i * 16 + 4 * g;
+      if (ob + 3 < n) rs[i] = *(const f32x4_t*)(rscale + ob);   // row tiles start on multiples of 4
+      else
+        for (int r = 0; r < 4; ++r) rs[i][r] = rscale[ob + r < n ? ob + r : n - 1];
+    }
+  }
   // D layout: column (query) = lane & 15, rows 4 g + r of each 16-row tile
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
@@ -315,14 +326,9 @@ __global__ __launch_bounds__(TG_WAVES * 64) void gemm_tiled_kernel(
       if constexpr (EB == 1) {   // per-row and per-query dequantisation scales
         const float qs = qscale[query];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          const int64_t ob = row0 + wm * TM + i * 16 + 4 * g;
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int64_t rr = ob + r < n ? ob + r : n - 1;
-            acc[i][j][r] *= rscale[rr] * qs;
-          }
-        }
+          for (int r = 0; r < 4; ++r) acc[i][j][r] *= rs[i][r] * qs;
       }
       if constexpr (FUSE) {
         // A lane holds MT * 4 scores of ONE query here.  It counts its survivors first and
