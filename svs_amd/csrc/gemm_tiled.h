@@ -31,6 +31,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "gemm_q16.h"
 #include "fp8.h"
 #include "gemv_f16.h"
@@ -334,30 +336,35 @@ __global__ __launch_bounds__(TG_WAVES * 64) void gemm_tiled_kernel(
         // A lane holds MT * 4 scores of ONE query here.  It counts its survivors first and
         // claims all their slots with ONE atomic (a returning atomic per surviving score made
         // each wave wait ~40 L2 round trips per tile: 24 of the 72 us a 256x256 tile took).
+        // Interior tiles (all but the last row tile) skip the row-bound checks.
         const float thr = fthr[(int64_t)query * fthr_stride];
-        uint32_t cnt = 0;
+        const int lr0 = wm * TM + 4 * g;                      // the lane's first row inside the tile
+        const int lim = (int)(n - row0 < BM ? n - row0 : BM);  // live rows of this tile
+        auto offer = [&](auto FULL) {
+          constexpr bool full = decltype(FULL)::value;
+          uint32_t cnt = 0;
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          const int64_t ob = row0 + wm * TM + i * 16 + 4 * g;
+          for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) cnt += (acc[i][j][r] >= thr && ob + r < n) ? 1u : 0u;
-        }
-        if (cnt) {
-          uint32_t slot = atomicAdd(fstate_words + (int64_t)query * fstate_stride, cnt);
-          uint64_t* cq = fcand + (int64_t)query * fcap;
+            for (int r = 0; r < 4; ++r) cnt += (acc[i][j][r] >= thr && (full || lr0 + i * 16 + r < lim)) ? 1u : 0u;
+          if (cnt) {
+            uint32_t slot = atomicAdd(fstate_words + (int64_t)query * fstate_stride, cnt);
+            uint64_t* cq = fcand + (int64_t)query * fcap;
+            const uint32_t row_lo = (uint32_t)(row0 + lr0);
 #pragma unroll
-          for (int i = 0; i < MT; ++i) {
-            const int64_t ob = row0 + wm * TM + i * 16 + 4 * g;
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float v = acc[i][j][r];
-              if (v >= thr && ob + r < n) {
-                if (slot < fcap) cq[slot] = ((uint64_t)score_key(v) << 32) | (uint32_t)(ob + r);
-                ++slot;
+              for (int r = 0; r < 4; ++r) {
+                const float v = acc[i][j][r];
+                if (v >= thr && (full || lr0 + i * 16 + r < lim)) {
+                  if (slot < fcap) cq[slot] = ((uint64_t)score_key(v) << 32) | (row_lo + (uint32_t)(i * 16 + r));
+                  ++slot;
+                }
               }
-            }
           }
-        }
+        };
+        if (lim == BM) offer(std::true_type{});
+        else offer(std::false_type{});
       } else {
         float* o = scores + (int64_t)query * sstride;
 #pragma unroll
