@@ -593,13 +593,19 @@ int launch_scores_tiled(const svs_index* idx, Ctx* c, const float* q_dev, int64_
                         int64_t sstride, FuseLaunch fl, hipStream_t st, bool restage = true) {
   if (idx->dtype == SVS_DTYPE_F32) {
     // exact-f32 MFMA runs at the vector rate: 32 queries per pass keep the kernel HBM-bound
-    // (62 % of the matrix pipe); larger batches are more passes of the same launch (grid y).
+    // (62 % of the matrix pipe); larger batches are more query tiles of the same launch (grid y).
+    // 64 queries per tile from 33 queries up (256 queries: 6.7 vs 7.3 ms with 32; 128-query tiles
+    // measured the same as 64: ~125 TFLOP/s of the 157 TF f32 MFMA peak)
+    const bool wide = nq > 32 && idx->variant.load() != 4;   // (variant 4: 32-query tiles, A/B)
     if (restage) {
       const float* qs = nullptr;
-      int rc = stage_queries_f32(idx, c, q_dev, nq, 32, &qs, st);
+      int rc = stage_queries_f32(idx, c, q_dev, nq, wide ? 64 : 32, &qs, st);
       if (rc != SVS_OK) return rc;
       c->q_f32 = qs;
     }
+    if (wide)
+      return fl.state ? launch_tiled_bn<64, true, 4>(idx, c, n_rows, nq, scores, sstride, fl, st)
+                      : launch_tiled_bn<64, false, 4>(idx, c, n_rows, nq, scores, sstride, fl, st);
     return fl.state ? launch_tiled_bn<32, true, 4>(idx, c, n_rows, nq, scores, sstride, fl, st)
                     : launch_tiled_bn<32, false, 4>(idx, c, n_rows, nq, scores, sstride, fl, st);
   }
