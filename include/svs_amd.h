@@ -108,6 +108,18 @@ int32_t svs_index_create_from_device(const float* dev_rows, int64_t n, int32_t d
  * 1.5x when needed.  Blocks searches on this handle while it runs. */
 int32_t svs_index_append(svs_index* idx, const float* host_rows, int64_t n_new);
 
+/* Same, from rows already in device memory on the index's device (f32, row stride src_ld
+ * elements): corpora generated or staged on the GPU block by block, so that the f32 source of a
+ * 10M x 3072 fp8 corpus (123 GB) never has to exist at once.  With svs_index_create(NULL, 0, d, ...)
+ * + svs_index_reserve() this builds an index of any size from device blocks without a
+ * reallocation.  Copies; does not alias. */
+int32_t svs_index_append_from_device(svs_index* idx, const float* dev_rows, int64_t n_new, int64_t src_ld);
+
+/* Grows the HBM buffers to hold rows_capacity rows (no-op when they already do), so that the
+ * appends that follow neither reallocate nor copy.  The matrix the reference builds is sized
+ * from SELECT COUNT(*) up front the same way (src/svs/kb.py:574-601). */
+int32_t svs_index_reserve(svs_index* idx, int64_t rows_capacity);
+
 /* Tombstones rows (GLOBAL indices, i.e. row_offset + local): they keep their index
  * (later rows do not shift, so the caller's emb_id_lookup stays valid) but can never
  * be returned again; count = min(k, n - masked).  Relative order of the surviving rows

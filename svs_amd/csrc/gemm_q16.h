@@ -170,7 +170,7 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void gemm_f32_q16_kernel(
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float v = acc[t][r];
-            if (v >= thr && ob + r < blk1) {
+            if (!(v < thr) && ob + r < blk1) {
               const uint64_t key = ((uint64_t)score_key(v) << 32) | (uint32_t)(ob + r);
               const uint32_t ls = atomicAdd(lcount, 1u);
               if (ls < (uint32_t)GEMM_LCAND) {
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void gemm_q16r_kernel(
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float v = out[r];
-          if (v >= thr && ob + r < blk1) {
+          if (!(v < thr) && ob + r < blk1) {
             const uint64_t key = ((uint64_t)score_key(v) << 32) | (uint32_t)(ob + r);
             const uint32_t ls = atomicAdd(lcount, 1u);
             if (ls < (uint32_t)GEMM_LCAND) {

@@ -75,7 +75,7 @@ __device__ __forceinline__ int tg_swz(int row) { return (row >> 1) & 7; }
 // Layout of the per-query header matches select.h: word 0 = n_cand, word 1 = flag.
 __device__ __forceinline__ void fuse_offer(uint32_t* hdr, uint64_t* cand, uint32_t cap, float thr, float v,
                                            uint32_t row) {
-  if (!(v >= thr)) return;
+  if (v < thr) return;   // (a NaN score passes: it ranks largest, keys.h)
   const uint32_t slot = atomicAdd(hdr, 1u);
   if (slot < cap) cand[slot] = ((uint64_t)score_key(v) << 32) | row;
 }
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(TG_WAVES * 64) void gemm_tiled_kernel(
 #pragma unroll
           for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) cnt += (acc[i][j][r] >= thr && (full || lr0 + i * 16 + r < lim)) ? 1u : 0u;
+            for (int r = 0; r < 4; ++r) cnt += (!(acc[i][j][r] < thr) && (full || lr0 + i * 16 + r < lim)) ? 1u : 0u;
           if (cnt) {
             uint32_t slot = atomicAdd(fstate_words + (int64_t)query * fstate_stride, cnt);
             uint64_t* cq = fcand + (int64_t)query * fcap;
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(TG_WAVES * 64) void gemm_tiled_kernel(
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 const float v = acc[i][j][r];
-                if (v >= thr && (full || lr0 + i * 16 + r < lim)) {
+                if (!(v < thr) && (full || lr0 + i * 16 + r < lim)) {
                   if (slot < fcap) cq[slot] = ((uint64_t)score_key(v) << 32) | (row_lo + (uint32_t)(i * 16 + r));
                   ++slot;
                 }

@@ -351,12 +351,14 @@ constexpr int FINAL_REG_KEYS = 32;   // per thread: lists of up to FINAL_THREADS
 // (out_rows[0] = -2) and re-run through the materialised path.
 __global__ __launch_bounds__(FINAL_THREADS) void select_final_kernel(
     const float* __restrict__ scores, int64_t n, int64_t score_stride, int k_out, int count,
-    int mode, uint32_t* __restrict__ scratch, const uint64_t* __restrict__ cand,
-    int64_t row_offset, float* __restrict__ out_scores, int64_t* __restrict__ out_rows) {
+    int mode, uint32_t* __restrict__ scratch, uint64_t* cand,
+    int64_t row_offset, float* __restrict__ out_scores, int64_t* __restrict__ out_rows,
+    const uint32_t* __restrict__ dead_bits = nullptr) {
   __shared__ uint64_t S[SORT_CAP];
   __shared__ uint32_t lh[RS_BINS];
   __shared__ uint32_t sh[256 + 2];
   __shared__ uint32_t s_cnt;
+  __shared__ uint32_t s_dead;
   const int qi = blockIdx.x;
   const float* s = scores + (int64_t)qi * score_stride;
   float* os = out_scores + (int64_t)qi * k_out;
@@ -367,10 +369,31 @@ __global__ __launch_bounds__(FINAL_THREADS) void select_final_kernel(
     for (int i = threadIdx.x; i < m; i += blockDim.x) S[i] = i < n ? make_key(s[i], (uint32_t)i) : 0ull;
   } else {
     SelHeader* hdr = (SelHeader*)(scratch + (int64_t)qi * SCR_WORDS);
-    const uint64_t* cq = cand + (int64_t)qi * CAND_CAP;
+    uint64_t* cq = cand + (int64_t)qi * CAND_CAP;
     const uint32_t flag = hdr->flag;
     const uint32_t n_cand = hdr->n_cand;
-    if (mode == 3 && (n_cand > (uint32_t)CAND_CAP || n_cand < (uint32_t)count)) {
+    // Tombstoned rows (svs_index_mask_rows) on the fused path: the GEMM epilogue does not know
+    // them, so their candidates are struck out here (key 0 sorts below every real key); the
+    // thresholds came from a prefix whose masked rows were already at -inf, so at least `count`
+    // live candidates remain.
+    uint32_t n_live = n_cand;
+    if (mode == 3 && dead_bits && n_cand <= (uint32_t)CAND_CAP) {
+      if (threadIdx.x == 0) s_dead = 0;
+      __syncthreads();
+      uint32_t dropped = 0;
+      for (uint32_t i = threadIdx.x; i < n_cand; i += blockDim.x) {
+        const uint32_t row = (uint32_t)cq[i];
+        if ((dead_bits[row >> 5] >> (row & 31)) & 1u) {
+          cq[i] = 0ull;
+          ++dropped;
+        }
+      }
+      if (dropped) atomicAdd(&s_dead, dropped);
+      __threadfence_block();
+      __syncthreads();
+      n_live = n_cand - s_dead;
+    }
+    if (mode == 3 && (n_cand > (uint32_t)CAND_CAP || n_live < (uint32_t)count)) {
       __syncthreads();
       uint32_t* w0 = scratch + (int64_t)qi * SCR_WORDS;
       for (int i = threadIdx.x; i < SCR_WORDS; i += blockDim.x) w0[i] = 0;
@@ -481,12 +504,14 @@ __global__ void mask_upper_triangle_kernel(float* __restrict__ S, int64_t n, int
 
 // ---- tombstones (svs_index_mask_rows) ------------------------------------------
 // scores[q][row] = -inf for every masked (tombstoned) row
+// (rows >= n_rows are skipped: the fused path materialises only a prefix of the corpus)
 __global__ void mask_dead_rows_kernel(float* __restrict__ scores, int64_t sstride, int nq,
-                                      const uint32_t* __restrict__ dead, int64_t n_dead) {
+                                      const uint32_t* __restrict__ dead, int64_t n_dead, int64_t n_rows) {
   const int64_t total = n_dead * nq;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
     const int64_t q = t / n_dead;
-    scores[q * sstride + dead[t - q * n_dead]] = -__builtin_inff();
+    const uint32_t r = dead[t - q * n_dead];
+    if ((int64_t)r < n_rows) scores[q * sstride + r] = -__builtin_inff();
   }
 }
 // pairwise matrix S[n][np]: whole row and column of a masked row -> -inf

@@ -96,6 +96,9 @@ struct svs_index {
   std::vector<uint32_t> dead_list;     // host copy of the masked (tombstoned) local rows
   uint32_t* dead_dev = nullptr;        // device copy
   size_t dead_dev_cap = 0;
+  std::vector<uint32_t> dead_bits;     // host bitmap, one bit per row (bit r & 31 of word r >> 5)
+  uint32_t* dead_bits_dev = nullptr;   // device copy: the fused top-k path drops masked candidates with it
+  size_t dead_bits_cap = 0;            // words
   int cu_count = 256;
 
   std::mutex mu;
@@ -146,6 +149,7 @@ void index_destroy(svs_index* idx) {
   (void)hipFree(idx->rows);
   (void)hipFree(idx->row_scales);
   (void)hipFree(idx->dead_dev);
+  (void)hipFree(idx->dead_bits_dev);
   delete idx;
 }
 
@@ -626,7 +630,7 @@ int run_select(svs_index* idx, Ctx* c, const float* scores, int64_t n_eff, int64
   int rc;
   if (n_eff <= SORT_CAP) {
     hipLaunchKernelGGL(select_final_kernel, dim3(nq), dim3(FINAL_THREADS), 0, st, scores, n_eff, sstride, k, count, 1,
-                       (uint32_t*)nullptr, (const uint64_t*)nullptr, row_offset, out_s, out_r);
+                       (uint32_t*)nullptr, (uint64_t*)nullptr, row_offset, out_s, out_r, (const uint32_t*)nullptr);
   } else if (count <= SEL_KMAX) {
     const int64_t per_block = (int64_t)FA_THREADS * SEL_VPT * 4;
     const unsigned blocks = (unsigned)((n_eff + per_block - 1) / per_block);
@@ -634,7 +638,7 @@ int run_select(svs_index* idx, Ctx* c, const float* scores, int64_t n_eff, int64
     hipLaunchKernelGGL(select_window_filter_kernel, dim3(blocks, nq), dim3(FA_THREADS), 0, st, scores, n_eff, sstride,
                        (uint32_t)count, c->hist, c->cand);
     hipLaunchKernelGGL(select_final_kernel, dim3(nq), dim3(FINAL_THREADS), 0, st, scores, n_eff, sstride, k, count, 0,
-                       c->hist, c->cand, row_offset, out_s, out_r);
+                       c->hist, c->cand, row_offset, out_s, out_r, (const uint32_t*)nullptr);
   } else {
     int64_t npad;
     next_pow2_i64(n_eff, &npad);
@@ -720,7 +724,7 @@ int enqueue_search(svs_index* idx, Ctx* c, const float* q_dev, int nq, int k, in
   const bool batched = uses_q16(idx, nq) || (nq >= 2 && tiled_ok(idx));
   const bool fused = allow_fused && path_a && batched && nq >= 16 &&
                      n >= 8 * FUSE_PREFIX_MIN && (int64_t)n < ((int64_t)1 << 32) &&
-                     count <= 256 && idx->dead_list.empty() && idx->variant.load() != 6;
+                     count <= 256 && idx->variant.load() != 6;
   const int64_t n_mat = fused ? fuse_prefix_rows(n) : n;     // rows of the materialised score matrix
   const int64_t sstride = (n_mat + 3) & ~(int64_t)3;         // float4-aligned score vectors
   if ((rc = grow_dev(&c->scores, &c->scores_cap, (size_t)nq * (size_t)sstride)) != SVS_OK) return rc;
@@ -754,6 +758,9 @@ int enqueue_search(svs_index* idx, Ctx* c, const float* q_dev, int nq, int k, in
     if ((rc = grow_dev(&c->pref_s, &c->pref_s_cap, (size_t)nq * (kth ? 1 : count))) != SVS_OK) return rc;
     if (!kth && (rc = grow_dev(&c->pref_r, &c->pref_r_cap, (size_t)nq * count)) != SVS_OK) return rc;
     if ((rc = launch_scores_any(idx, c, q_dev, n_mat, nq, c->scores, sstride, FuseLaunch{}, st)) != SVS_OK) return rc;
+    if (!idx->dead_list.empty())   // thresholds must come from LIVE rows: masked prefix rows -> -inf (rows past the prefix are skipped)
+      hipLaunchKernelGGL(mask_dead_rows_kernel, dim3(64), dim3(256), 0, st, c->scores, sstride, nq, idx->dead_dev,
+                         (int64_t)idx->dead_list.size(), n_mat);
     if (kth)
       hipLaunchKernelGGL(prefix_kth_kernel, dim3(nq), dim3(FINAL_THREADS), 0, st, (const float*)c->scores, n_mat, sstride, count, c->pref_s);
     else if ((rc = run_select(idx, c, c->scores, n_mat, sstride, nq, count, count, c->pref_s, c->pref_r, st, idx->row_offset)) != SVS_OK)
@@ -763,12 +770,13 @@ int enqueue_search(svs_index* idx, Ctx* c, const float* q_dev, int nq, int k, in
     if ((rc = launch_scores_any(idx, c, q_dev, n, nq, nullptr, 0, fl, st, false)) != SVS_OK) return rc;
     if (timed) HIP_TRY(hipEventRecord(ev.e1, st));
     hipLaunchKernelGGL(select_final_kernel, dim3(nq), dim3(FINAL_THREADS), 0, st, (const float*)nullptr, n, (int64_t)0, k, count, 3,
-                       c->hist, c->cand, idx->row_offset, out_s, out_r);
+                       c->hist, c->cand, idx->row_offset, out_s, out_r,
+                       (const uint32_t*)(idx->dead_list.empty() ? nullptr : idx->dead_bits_dev));
   } else {
     if ((rc = launch_scores_any(idx, c, q_dev, n, nq, c->scores, sstride, FuseLaunch{}, st)) != SVS_OK) return rc;
     if (!idx->dead_list.empty())   // tombstoned rows can never be returned
       hipLaunchKernelGGL(mask_dead_rows_kernel, dim3(64), dim3(256), 0, st, c->scores, sstride, nq, idx->dead_dev,
-                         (int64_t)idx->dead_list.size());
+                         (int64_t)idx->dead_list.size(), n);
     if (timed) HIP_TRY(hipEventRecord(ev.e1, st));
     if (k > 0 && (rc = run_select(idx, c, c->scores, n, sstride, nq, k, count, out_s, out_r, st, idx->row_offset)) != SVS_OK) return rc;
   }
@@ -780,6 +788,18 @@ int enqueue_search(svs_index* idx, Ctx* c, const float* q_dev, int nq, int k, in
   }
   return SVS_OK;
 }
+
+// Holds one reference for the duration of a call.  Declared BEFORE the geometry lock in every
+// entry point: locals unwind in reverse order, so the lock is dropped first and only then the
+// reference -- if a concurrent svs_index_release() made ours the last one, index_destroy() must
+// not run while this call still holds idx->rw.
+struct RefGuard {
+  svs_index* i;
+  explicit RefGuard(svs_index* idx) : i(idx) { i->refs.fetch_add(1); }
+  ~RefGuard() { svs_index_release(i); }
+  RefGuard(const RefGuard&) = delete;
+  RefGuard& operator=(const RefGuard&) = delete;
+};
 
 int check_query_args(const svs_index* idx, const void* q, int nq, int d) {
   if (!idx) return fail(SVS_ERR_INVALID, "null index");
@@ -869,6 +889,79 @@ int choose_ld(int d, int dtype) {
   if ((int64_t)waved * 8 <= (int64_t)tight * 9) return waved;
   if ((int64_t)lined * 8 <= (int64_t)tight * 9) return lined;
   return tight;
+}
+
+// Device rows [0, nrows) (f32, stride src_ld) -> HBM rows [row0, row0 + nrows) of the index's layout.
+hipError_t copy_device_rows(svs_index* idx, const float* dev_rows, int64_t nrows, int64_t src_ld, int64_t row0) {
+  const int d = idx->d;
+  hipError_t e = hipSuccess;
+  if (idx->dtype == SVS_DTYPE_F16) {
+    hipLaunchKernelGGL(convert_rows_f16_kernel, dim3(4096), dim3(256), 0, 0, dev_rows, nrows, d, src_ld,
+                       (_Float16*)idx->rows + (size_t)row0 * idx->ld, idx->ld);
+    e = hipGetLastError();
+  } else if (idx->dtype == SVS_DTYPE_FP8) {
+    hipLaunchKernelGGL(quantize_rows_fp8_kernel, dim3(4096), dim3(256), 0, 0, dev_rows, nrows, d, src_ld,
+                       (uint8_t*)idx->rows + (size_t)row0 * idx->ld, idx->ld, idx->row_scales + row0, (float*)nullptr);
+    e = hipGetLastError();
+  } else {
+    float* dst = (float*)idx->rows + (size_t)row0 * idx->ld;
+    if (idx->ld != d) e = hipMemset(dst, 0, (size_t)nrows * idx->ld * sizeof(float));
+    if (e == hipSuccess)
+      e = hipMemcpy2D(dst, (size_t)idx->ld * sizeof(float), dev_rows, (size_t)src_ld * sizeof(float),
+                      (size_t)d * sizeof(float), (size_t)nrows, hipMemcpyDeviceToDevice);
+  }
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  return e;
+}
+
+// Device bitmap of the masked rows, one bit per row of the current capacity (caller holds the
+// geometry lock exclusively).  Nothing is allocated while no row is masked.
+int sync_dead_bits(svs_index* idx) {
+  if (idx->dead_list.empty()) return SVS_OK;
+  const size_t words = (size_t)((std::max(idx->cap, idx->n) + 31) / 32);
+  idx->dead_bits.assign(words, 0u);
+  for (uint32_t r : idx->dead_list) idx->dead_bits[r >> 5] |= 1u << (r & 31);
+  if (words > idx->dead_bits_cap) {
+    HIP_TRY(hipDeviceSynchronize());   // enqueued searches may still read the old bitmap
+    (void)hipFree(idx->dead_bits_dev);
+    idx->dead_bits_dev = nullptr;
+    idx->dead_bits_cap = 0;
+    HIP_TRY(hipMalloc((void**)&idx->dead_bits_dev, words * sizeof(uint32_t)));
+    idx->dead_bits_cap = words;
+  }
+  HIP_TRY(hipMemcpy(idx->dead_bits_dev, idx->dead_bits.data(), words * sizeof(uint32_t), hipMemcpyHostToDevice));
+  return SVS_OK;
+}
+
+// Makes room for `rows` rows (caller holds the geometry lock exclusively).  exact == false grows
+// by 1.5x (amortised appends); exact == true (svs_index_reserve) allocates just `rows`.
+int ensure_capacity(svs_index* idx, int64_t rows, bool exact) {
+  if (rows > 0xffffffffll) return fail(SVS_ERR_INVALID, "at most 2^32 rows per handle; shard the corpus");
+  if (rows <= idx->cap) return SVS_OK;
+  const size_t esz = idx->dtype == SVS_DTYPE_F32 ? 4 : (idx->dtype == SVS_DTYPE_F16 ? 2 : 1), row_b = (size_t)idx->ld * esz;
+  const int64_t new_cap = exact ? rows : std::max<int64_t>(rows, idx->cap + idx->cap / 2 + 1024);
+  void* nrows = nullptr;
+  float* nscales = nullptr;
+  HIP_TRY(hipMalloc(&nrows, (size_t)new_cap * row_b));
+  if (idx->dtype == SVS_DTYPE_FP8) {
+    hipError_t e = hipMalloc((void**)&nscales, (size_t)new_cap * sizeof(float));
+    if (e != hipSuccess) {
+      (void)hipFree(nrows);
+      return fail(SVS_ERR_NOMEM, "hipMalloc(row scales): %s", hipGetErrorString(e));
+    }
+  }
+  // work already enqueued by the device API may still read the old buffers
+  HIP_TRY(hipDeviceSynchronize());
+  const int64_t n_old = idx->n;
+  if (n_old) HIP_TRY(hipMemcpy(nrows, idx->rows, (size_t)n_old * row_b, hipMemcpyDeviceToDevice));
+  if (n_old && nscales) HIP_TRY(hipMemcpy(nscales, idx->row_scales, (size_t)n_old * sizeof(float), hipMemcpyDeviceToDevice));
+  (void)hipFree(idx->rows);
+  (void)hipFree(idx->row_scales);
+  idx->rows = nrows;
+  idx->row_scales = nscales;
+  idx->cap = new_cap;
+  idx->bytes = (size_t)new_cap * row_b + (idx->dtype == SVS_DTYPE_FP8 ? (size_t)new_cap * sizeof(float) : 0);
+  return SVS_OK;
 }
 
 int create_common(int64_t n, int32_t d, int32_t store_dtype, int32_t device, int64_t row_offset,
@@ -970,22 +1063,7 @@ int32_t svs_index_create_from_device(const float* dev_rows, int64_t n, int32_t d
       index_destroy(idx);
       return fail(SVS_ERR_INVALID, "bad device source (ptr %p, ld %lld)", (const void*)dev_rows, (long long)src_ld);
     }
-    hipError_t e = hipSuccess;
-    if (idx->dtype == SVS_DTYPE_F16) {
-      hipLaunchKernelGGL(convert_rows_f16_kernel, dim3(4096), dim3(256), 0, 0, dev_rows, n, d, src_ld,
-                         (_Float16*)idx->rows, idx->ld);
-      e = hipGetLastError();
-    } else if (idx->dtype == SVS_DTYPE_FP8) {
-      hipLaunchKernelGGL(quantize_rows_fp8_kernel, dim3(4096), dim3(256), 0, 0, dev_rows, n, d, src_ld,
-                         (uint8_t*)idx->rows, idx->ld, idx->row_scales, (float*)nullptr);
-      e = hipGetLastError();
-    } else {
-      if (idx->ld != d) e = hipMemset(idx->rows, 0, idx->bytes);
-      if (e == hipSuccess)
-        e = hipMemcpy2D(idx->rows, (size_t)idx->ld * sizeof(float), dev_rows, (size_t)src_ld * sizeof(float),
-                        (size_t)d * sizeof(float), (size_t)n, hipMemcpyDeviceToDevice);
-    }
-    if (e == hipSuccess) e = hipDeviceSynchronize();
+    hipError_t e = copy_device_rows(idx, dev_rows, n, src_ld, 0);
     if (e != hipSuccess) {
       index_destroy(idx);
       return fail(SVS_ERR_DEVICE, "device corpus copy: %s", hipGetErrorString(e));
@@ -1004,36 +1082,39 @@ int32_t svs_index_append(svs_index* idx, const float* host_rows, int64_t n_new) 
   std::unique_lock<std::shared_mutex> geo(idx->rw);   // no search is enqueuing while the geometry changes
   HIP_TRY(hipSetDevice(idx->device));
   const int64_t n_old = idx->n, n_tot = n_old + n_new;
-  if (n_tot > 0xffffffffll) return fail(SVS_ERR_INVALID, "at most 2^32 rows per handle; shard the corpus");
-  const size_t esz = elem_bytes(idx), row_b = (size_t)idx->ld * esz;
-  if (n_tot > idx->cap) {
-    // grow by 1.5x; work already enqueued by the device API may still read the old buffers
-    const int64_t new_cap = std::max<int64_t>(n_tot, idx->cap + idx->cap / 2 + 1024);
-    void* nrows = nullptr;
-    float* nscales = nullptr;
-    HIP_TRY(hipMalloc(&nrows, (size_t)new_cap * row_b));
-    if (idx->dtype == SVS_DTYPE_FP8) {
-      hipError_t e = hipMalloc((void**)&nscales, (size_t)new_cap * sizeof(float));
-      if (e != hipSuccess) {
-        (void)hipFree(nrows);
-        return fail(SVS_ERR_NOMEM, "hipMalloc(row scales): %s", hipGetErrorString(e));
-      }
-    }
-    HIP_TRY(hipDeviceSynchronize());
-    if (n_old) HIP_TRY(hipMemcpy(nrows, idx->rows, (size_t)n_old * row_b, hipMemcpyDeviceToDevice));
-    if (n_old && nscales) HIP_TRY(hipMemcpy(nscales, idx->row_scales, (size_t)n_old * sizeof(float), hipMemcpyDeviceToDevice));
-    (void)hipFree(idx->rows);
-    (void)hipFree(idx->row_scales);
-    idx->rows = nrows;
-    idx->row_scales = nscales;
-    idx->cap = new_cap;
-  }
+  int rc = ensure_capacity(idx, n_tot, false);
+  if (rc != SVS_OK) return rc;
   hipError_t e = upload_host_rows(idx, host_rows, n_new, n_old);
   if (e != hipSuccess) return fail(SVS_ERR_DEVICE, "append upload: %s", hipGetErrorString(e));
   idx->n = n_tot;
   idx->dead_flag.resize((size_t)n_tot, 0);
-  idx->bytes = (size_t)idx->cap * row_b + (idx->dtype == SVS_DTYPE_FP8 ? (size_t)idx->cap * sizeof(float) : 0);
-  return SVS_OK;
+  return sync_dead_bits(idx);
+}
+
+int32_t svs_index_reserve(svs_index* idx, int64_t rows_capacity) {
+  if (!idx) return fail(SVS_ERR_INVALID, "null index");
+  if (idx->d == 0) return fail(SVS_ERR_SHAPE, "cannot reserve rows of a zero-dimensional index");
+  std::unique_lock<std::shared_mutex> geo(idx->rw);
+  HIP_TRY(hipSetDevice(idx->device));
+  return ensure_capacity(idx, rows_capacity, true);
+}
+
+int32_t svs_index_append_from_device(svs_index* idx, const float* dev_rows, int64_t n_new, int64_t src_ld) {
+  if (!idx) return fail(SVS_ERR_INVALID, "null index");
+  if (n_new < 0) return fail(SVS_ERR_INVALID, "negative row count");
+  if (n_new == 0) return SVS_OK;
+  if (idx->d == 0) return fail(SVS_ERR_SHAPE, "cannot append to a zero-dimensional index");
+  if (!dev_rows || src_ld < idx->d) return fail(SVS_ERR_INVALID, "bad device source (ptr %p, ld %lld)", (const void*)dev_rows, (long long)src_ld);
+  std::unique_lock<std::shared_mutex> geo(idx->rw);
+  HIP_TRY(hipSetDevice(idx->device));
+  const int64_t n_old = idx->n, n_tot = n_old + n_new;
+  int rc = ensure_capacity(idx, n_tot, false);
+  if (rc != SVS_OK) return rc;
+  hipError_t e = copy_device_rows(idx, dev_rows, n_new, src_ld, n_old);
+  if (e != hipSuccess) return fail(SVS_ERR_DEVICE, "device append: %s", hipGetErrorString(e));
+  idx->n = n_tot;
+  idx->dead_flag.resize((size_t)n_tot, 0);
+  return sync_dead_bits(idx);
 }
 
 int32_t svs_index_mask_rows(svs_index* idx, const int64_t* rows, int64_t count) {
@@ -1055,6 +1136,10 @@ int32_t svs_index_mask_rows(svs_index* idx, const int64_t* rows, int64_t count) 
   }
   if (!changed) return SVS_OK;
   HIP_TRY(hipSetDevice(idx->device));
+  {
+    int rc = sync_dead_bits(idx);
+    if (rc != SVS_OK) return rc;
+  }
   if (idx->dead_list.size() > idx->dead_dev_cap) {
     HIP_TRY(hipDeviceSynchronize());   // enqueued searches may still read the old list
     (void)hipFree(idx->dead_dev);
@@ -1096,6 +1181,7 @@ int32_t svs_index_info(const svs_index* idx, svs_index_info_t* out) {
 int32_t svs_index_search(svs_index* idx, const float* queries, int32_t nq, int32_t d, int32_t k,
                          float* out_scores, int64_t* out_rows, int32_t* out_count) {
   if (!idx) return fail(SVS_ERR_INVALID, "null index");
+  RefGuard guard(idx);
   std::shared_lock<std::shared_mutex> geo(idx->rw);
   int rc = check_query_args(idx, queries, nq, d);
   if (rc != SVS_OK) return rc;
@@ -1103,8 +1189,6 @@ int32_t svs_index_search(svs_index* idx, const float* queries, int32_t nq, int32
   if (out_count) *out_count = count;
   if (nq == 0 || count == 0) return SVS_OK;
   if (!out_scores || !out_rows) return fail(SVS_ERR_INVALID, "null output");
-  svs_index_retain(idx);
-  struct Guard { svs_index* i; ~Guard() { svs_index_release(i); } } guard{idx};
   HIP_TRY(hipSetDevice(idx->device));
   Ctx* c = nullptr;
   if ((rc = ctx_acquire(idx, nullptr, true, &c)) != SVS_OK) return rc;
@@ -1156,6 +1240,7 @@ int32_t svs_index_search_device(svs_index* idx, const float* dev_queries, int32_
                                 int32_t k, float* dev_out_scores, int64_t* dev_out_rows,
                                 int32_t* out_count, void* hip_stream) {
   if (!idx) return fail(SVS_ERR_INVALID, "null index");
+  RefGuard guard(idx);
   std::shared_lock<std::shared_mutex> geo(idx->rw);
   int rc = check_query_args(idx, dev_queries, nq, d);
   if (rc != SVS_OK) return rc;
@@ -1163,8 +1248,6 @@ int32_t svs_index_search_device(svs_index* idx, const float* dev_queries, int32_
   if (out_count) *out_count = count;
   if (nq == 0 || k <= 0) return SVS_OK;
   if (!dev_out_scores || !dev_out_rows) return fail(SVS_ERR_INVALID, "null output");
-  svs_index_retain(idx);
-  struct Guard { svs_index* i; ~Guard() { svs_index_release(i); } } guard{idx};
   HIP_TRY(hipSetDevice(idx->device));
   hipStream_t st = (hipStream_t)hip_stream;
   Ctx* c = nullptr;
@@ -1181,12 +1264,11 @@ int32_t svs_index_search_device(svs_index* idx, const float* dev_queries, int32_
 
 int32_t svs_index_scores(svs_index* idx, const float* query, int32_t d, float* out_scores) {
   if (!idx) return fail(SVS_ERR_INVALID, "null index");
+  RefGuard guard(idx);
   std::shared_lock<std::shared_mutex> geo(idx->rw);
   int rc = check_query_args(idx, query, 1, d);
   if (rc != SVS_OK) return rc;
   if (!out_scores) return fail(SVS_ERR_INVALID, "null output");
-  svs_index_retain(idx);
-  struct Guard { svs_index* i; ~Guard() { svs_index_release(i); } } guard{idx};
   HIP_TRY(hipSetDevice(idx->device));
   Ctx* c = nullptr;
   if ((rc = ctx_acquire(idx, nullptr, true, &c)) != SVS_OK) return rc;
@@ -1204,6 +1286,7 @@ int32_t svs_index_scores(svs_index* idx, const float* query, int32_t d, float* o
 int32_t svs_index_top_pairs(svs_index* idx, int32_t k, float* out_scores, int64_t* out_i, int64_t* out_j,
                             int32_t* out_count) {
   if (!idx) return fail(SVS_ERR_INVALID, "null index");
+  RefGuard guard(idx);
   std::shared_lock<std::shared_mutex> geo(idx->rw);
   const int64_t n = idx->n;
   const int64_t np = (n + 3) & ~(int64_t)3;
@@ -1214,8 +1297,6 @@ int32_t svs_index_top_pairs(svs_index* idx, int32_t k, float* out_scores, int64_
   if (count == 0) return SVS_OK;
   if (!out_scores || !out_i || !out_j) return fail(SVS_ERR_INVALID, "null output");
   if (n * np > 0xffffffffll) return fail(SVS_ERR_UNSUPPORTED, "pairwise scores need n*n <= 2^32 (n = %lld)", (long long)n);
-  svs_index_retain(idx);
-  struct Guard { svs_index* i; ~Guard() { svs_index_release(i); } } guard{idx};
   HIP_TRY(hipSetDevice(idx->device));
   Ctx* c = nullptr;
   int rc;

@@ -104,6 +104,13 @@ class DeviceIndex:
         except Exception:
             pass
 
+    def _live_rows(self) -> int:
+        """Rows a search can return right now (the handle may have been appended to or
+        masked through another owner since this object last looked)."""
+        info = _native.IndexInfo()
+        _native.check(self._lib.svs_index_info(self._handle(), C.byref(info)))
+        return max(int(info.n) - int(info.n_masked), 0)
+
     def _pinned_handle(self) -> int:
         """retain() under the lock so a concurrent release() cannot free the
         handle between reading it and entering the library."""
@@ -120,6 +127,30 @@ class DeviceIndex:
         if m.ndim != 2 or (m.shape[0] and m.shape[1] != self.d):
             raise ValueError(f"cannot append shape {m.shape} to an index of dimension {self.d}")
         _native.check(self._lib.svs_index_append(self._handle(), m.ctypes.data_as(C.c_void_p), m.shape[0]))
+        self._refresh()
+
+    @classmethod
+    def empty(cls, d: int, device: int = 0, row_offset: int = 0, dtype: str = "f32",
+              reserve: int = 0) -> "DeviceIndex":
+        """An index of dimension ``d`` with no rows yet (optionally with room for ``reserve`` rows),
+        to be filled with ``append`` / ``append_device`` block by block -- the way a cold start
+        streams BLOBs out of SQLite without ever holding the whole matrix on the host."""
+        lib = _native.load()
+        out = C.c_void_p()
+        _native.check(lib.svs_index_create(None, 0, int(d), _DTYPES[dtype], int(device), int(row_offset), C.byref(out)))
+        idx = cls(None, _handle=out.value)
+        if reserve > 0:
+            idx.reserve(reserve)
+        return idx
+
+    def reserve(self, rows: int) -> None:
+        _native.check(self._lib.svs_index_reserve(self._handle(), int(rows)))
+        self._refresh()
+
+    def append_device(self, ptr: int, n: int, src_ld: Optional[int] = None) -> None:
+        """``append`` for f32 rows already in this device's memory (raw device address)."""
+        _native.check(self._lib.svs_index_append_from_device(
+            self._handle(), C.c_void_p(ptr), int(n), int(src_ld if src_ld is not None else self.d)))
         self._refresh()
 
     def mask_rows(self, rows) -> None:
@@ -146,7 +177,9 @@ class DeviceIndex:
         if q.ndim != 2:
             raise ValueError(f"queries must be 2-D, got shape {q.shape}")
         nq, d = q.shape
-        k = max(n, 0)
+        # clamp before allocating and before the int32 argument (reference src/svs/util.py:198-199
+        # clamps top_k to len(scores) first): k = 2**32 must mean "rank everything", not 0
+        k = min(max(n, 0), self._live_rows())
         scores = np.empty((nq, k), dtype=np.float32)
         rows = np.empty((nq, k), dtype=np.int64)
         count = C.c_int32(0)
@@ -201,7 +234,8 @@ class DeviceIndex:
         """``get_top_pairs(np.dot(M, M.T), n)`` (reference src/svs/kb.py:1651,
         src/svs/util.py:206-233): [(score, row_i, row_j)] with i < j."""
         assert isinstance(n, int)
-        k = max(n, 0)
+        live = self._live_rows()
+        k = min(max(n, 0), live * (live - 1) // 2)   # reference src/svs/util.py:198-199 on the pair list
         scores = np.empty(k, dtype=np.float32)
         ri = np.empty(k, dtype=np.int64)
         rj = np.empty(k, dtype=np.int64)

@@ -30,3 +30,29 @@ def gpu():
     n = _native.device_count()
     assert n > 0, "no HIP device visible: -m gpu tests need a real MI355X"
     return n
+
+
+# ---- parity record: near-tie swap counts of the golden search cases -------------------------
+# tests/test_search_gpu.py::test_search_golden files, per golden case, how many ranks differed
+# from the reference's recorded row order (single-query path and batch path separately).  The
+# table is printed in the terminal summary (so it lands in the driver's GPU test log) and written
+# to gpurun_out/parity_swaps.json (merged back from the GPU box).
+PARITY_SWAPS = {}
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    if not PARITY_SWAPS:
+        return
+    import json
+    tr = terminalreporter
+    tr.write_sep("-", "parity: ranks that differ from the reference's golden row order")
+    for name, rec in PARITY_SWAPS.items():
+        tr.write_line(f"{name}: single-query path {rec['single']}, batch path {rec['batch']} "
+                      f"(min adjacent f64 gap {rec['min_gap']})")
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, "parity_swaps.json"), "w") as f:
+            json.dump(PARITY_SWAPS, f, indent=1)
+    except OSError:
+        pass

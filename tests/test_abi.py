@@ -76,3 +76,33 @@ def test_header_is_plain_c_and_links(tmp_path):
                     "-Wl,-rpath,/opt/rocm/lib"], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0 and "svs_amd" in out.stdout, (out.returncode, out.stdout, out.stderr)
+
+
+def _build_c(tmp_path, name, extra=()):
+    import subprocess
+    lib_dir = os.path.join(ROOT, "svs_amd", "lib")
+    exe = tmp_path / name
+    subprocess.run(["gcc", "-std=gnu99", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "c", name + ".c"), "-o", str(exe), "-L", lib_dir, "-lsvs_amd", "-lpthread",
+                    "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", *extra], check=True)
+    return exe
+
+
+def test_c_release_race_program_builds(tmp_path):
+    """CPU: the pure-C race test (tests/c/release_race.c) compiles and links against the ABI."""
+    import shutil
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    assert os.path.exists(_build_c(tmp_path, "release_race"))
+
+
+@pytest.mark.gpu
+def test_c_caller_release_races_with_search(gpu, tmp_path):
+    """A C caller (no Python wrapper pinning the handle) releases the only owner reference while a
+    search is in flight on another thread: include/svs_amd.h allows exactly this.  The search's own
+    reference must outlive its geometry lock (the lock guard used to be destroyed after
+    the last unref, i.e. on freed memory)."""
+    import subprocess
+    exe = _build_c(tmp_path, "release_race")
+    out = subprocess.run([str(exe), "12"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.startswith("ok"), (out.returncode, out.stdout, out.stderr)

@@ -28,6 +28,52 @@ def test_fp8_quantisation_matches_ocp_e4m3(gpu):
     idx.release()
 
 
+def _e4m3_external(x):
+    """x (.., d) f32 -> (dequantised f32, scale): the library's recipe restated with torch's CPU
+    float8_e4m3fn cast (RNE): scale = max|x| / 448 per vector, q = e4m3(x * (1 / scale))."""
+    import torch
+    x = np.asarray(x, dtype=np.float32)
+    scale = (np.abs(x).max(axis=-1, keepdims=True) / np.float32(448.0)).astype(np.float32)
+    q = torch.from_numpy((x * (np.float32(1.0) / scale)).astype(np.float32)).to(torch.float8_e4m3fn).to(torch.float32).numpy()
+    return q * scale, scale
+
+
+def test_fp8_query_quantiser_external(gpu):
+    """The QUERY side of the fp8 path against something that is not the library: torch's CPU
+    e4m3fn cast.  Vectors are built so that their scale is an exact power of two (max|x| =
+    448 * 2^-12): 1 / scale and every x / scale are then exact in f32, so there are no rounding
+    ties of the division left and the comparison is bit for bit.  Checked three ways: the
+    quantised query read back (stored_query), the scores the single-query kernel returns, and the
+    top-k of the batched MFMA kernel -- both against numpy on the EXTERNALLY quantised corpus and
+    query, so a quantiser bug on either side shows as a score difference of ~1e-4, not 1e-5."""
+    from svs_amd import DeviceIndex
+    top = np.float32(448.0 * 2.0 ** -12)
+    m, qs = corpus_and_query("gaussian", 77, 6000, 512, 20)
+    m = np.clip(m, -top, top)
+    qs = np.clip(qs, -top, top)
+    m[:, 3] = top
+    qs[:, 5] = -top
+    idx = DeviceIndex(m, dtype="fp8")
+    rows_ext, rscale = _e4m3_external(m)
+    assert np.all(rscale == np.float32(2.0 ** -12))
+    assert np.array_equal(idx.stored_rows(), rows_ext)
+    q_ext = []
+    for q in qs:
+        qe, qscale = _e4m3_external(q)
+        assert qscale[0] == np.float32(2.0 ** -12)
+        assert np.array_equal(idx.stored_query(q), qe)          # the query quantiser, bit for bit
+        q_ext.append(qe)
+        got = idx.scores(q)                                      # what the kernel really multiplies
+        exp = rows_ext.astype(np.float64) @ qe.astype(np.float64)
+        assert np.max(np.abs(got - exp)) <= 1e-5, np.max(np.abs(got - exp))
+    bs, br = idx.search_batch(qs, 50)                            # MFMA path, 20 queries
+    for qi, qe in enumerate(q_ext):
+        exp = oracle.cpu_search(rows_ext, qe, 50)
+        assert_topk_parity(bs[qi], br[qi], [s for s, _ in exp], [i for _, i in exp],
+                           oracle.cpu_scores_f64(rows_ext, qe), label=f"fp8 external q{qi}")
+    idx.release()
+
+
 @pytest.mark.parametrize("n,d,k", [(20000, 3072, 100), (20000, 1536, 100), (6000, 1024, 10), (5000, 100, 7),
                                    (600, 3, 5), (50, 1537, 100)])
 def test_fp8_single_query(gpu, n, d, k):

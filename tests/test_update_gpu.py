@@ -116,3 +116,89 @@ def test_append_while_searching(gpu):
     assert not errs, errs
     assert [idx.search(q, 30) for q in qs] == after and before != after
     idx.release()
+
+
+@pytest.mark.parametrize("dtype,d,nq", [("f32", 1536, 16), ("f32", 512, 40), ("f16", 1536, 32), ("fp8", 1024, 64)])
+def test_masked_rows_keep_the_fused_topk(gpu, dtype, d, nq):
+    """One tombstone used to switch every batched search back to the materialised path (an
+    nq x n score matrix per context).  Now the fused epilogue stays on: the prefix thresholds
+    come from live rows only and select_final strikes masked candidates out.  >= 131,072 rows,
+    >= 16 queries: equals the oracle on the compacted matrix and the materialised run of the
+    same kernels (set_variant(6)) bit for bit -- and no nq x n matrix is allocated."""
+    from svs_amd import DeviceIndex, _native
+    n, k = 140000, 100
+    m, qs = corpus_and_query("gaussian", 700 + d + nq, n, d, nq)
+    idx = DeviceIndex(m, dtype=dtype)
+    clean_s, clean_r = idx.search_batch(qs, k)
+    rng = np.random.default_rng(5)
+    dead = np.unique(np.concatenate([
+        rng.choice(n, 3000, replace=False),
+        clean_r[:, :30].ravel(),              # the 30 best rows of every query: winners must be replaced
+        np.arange(0, 2000, 3),                # a good part of the prefix that seeds the thresholds
+        [0, n - 1]]))
+    idx.mask_rows(dead)
+    free_before, _ = _native.device_memory(0)
+    fs, fr = idx.search_batch(qs, k)
+    free_after, _ = _native.device_memory(0)
+    # the materialised path would have grown the context's score buffer to nq * n * 4 bytes
+    assert free_before - free_after < nq * n * 4 // 2, "fused path fell back to a materialised score matrix"
+    assert not np.isin(fr, dead).any()
+    live = np.setdiff1d(np.arange(n), dead)
+    md = idx.stored_rows()[live]
+    for qi in range(0, nq, max(1, nq // 8)):
+        qd = idx.stored_query(qs[qi])
+        exp = oracle.cpu_search(md, qd, k)
+        truth = np.full(n, -np.inf); truth[live] = oracle.cpu_scores_f64(md, qd)
+        assert_topk_parity(fs[qi], fr[qi], [s for s, _ in exp], [int(live[i]) for _, i in exp], truth,
+                           label=f"{dtype} masked fused q{qi}")
+    idx.set_variant(6)
+    ms, mr = idx.search_batch(qs, k)
+    assert np.array_equal(mr, fr) and np.array_equal(ms, fs)
+    idx.set_variant(0)
+    # rows appended after masking are searchable and the old tombstones still hold
+    extra = m[dead[:50]]
+    idx.append(extra)
+    s2, r2 = idx.search_batch(qs, k)
+    assert not np.isin(r2, dead).any()
+    ref_rows = np.concatenate([md, idx.stored_rows(n, 50)])
+    ref_ids = np.concatenate([live, np.arange(n, n + 50)])
+    for qi in (0, nq - 1):
+        qd = idx.stored_query(qs[qi])
+        exp = oracle.cpu_search(ref_rows, qd, k)
+        truth = np.full(n + 50, -np.inf); truth[ref_ids] = oracle.cpu_scores_f64(ref_rows, qd)
+        assert_topk_parity(s2[qi], r2[qi], [s for s, _ in exp], [int(ref_ids[i]) for _, i in exp], truth,
+                           label=f"{dtype} masked fused + append q{qi}")
+    idx.release()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16", "fp8"])
+def test_build_from_device_blocks(gpu, dtype):
+    """svs_index_create(NULL, 0, d) + svs_index_reserve + svs_index_append_from_device: an index
+    assembled from device blocks equals the one uploaded from the host in one go, bit for bit."""
+    import torch
+    from svs_amd import DeviceIndex
+    n, d = 50000, 1000            # d = 1000: rows padded to ld = 1024 (f32) -- the 2-D copy path
+    m, qs = corpus_and_query("gaussian", 61, n, d, 20)
+    ref = DeviceIndex(m, dtype=dtype)
+    idx = DeviceIndex.empty(d, dtype=dtype, reserve=30000)
+    assert idx.shape == (0, d)
+    with pytest.raises(ValueError):
+        idx.search(qs[0], 5)       # empty matrix: the reference raises ValueError too
+    for r0, r1 in ((0, 1), (1, 20000), (20000, 30000), (30000, 50000)):   # the last block outgrows the reservation
+        blk = torch.from_numpy(m[r0:r1]).to("cuda:0")
+        idx.append_device(blk.data_ptr(), r1 - r0)
+        del blk
+    assert idx.shape == (n, d) and idx.hbm_bytes >= ref.hbm_bytes
+    assert np.array_equal(idx.stored_rows(), ref.stored_rows())
+    for q in qs[:3]:
+        assert idx.search(q, 100) == ref.search(q, 100)
+    a, b = idx.search_batch(qs, 50), ref.search_batch(qs, 50)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    # strided device source
+    wide = torch.zeros((100, d + 24), device="cuda:0")
+    wide[:, :d] = torch.from_numpy(m[:100]).to("cuda:0")
+    idx.append_device(wide.data_ptr(), 100, src_ld=d + 24)
+    assert np.array_equal(idx.stored_rows(n, 100), ref.stored_rows(0, 100))
+    with pytest.raises(ValueError):
+        idx.append_device(wide.data_ptr(), 10, src_ld=d - 1)
+    idx.release(); ref.release()
