@@ -273,8 +273,8 @@ def test_config4_fp8_10m_rows_b256(gpu):
         ms, mr = idx.search_batch(qh[q0:q0 + 64], k)
         assert np.array_equal(mr, fr[q0:q0 + 64]) and np.array_equal(ms, fs[q0:q0 + 64]), f"queries {q0}.."
     idx.set_variant(0)
-    for qi in (0, 11, 255):
-        one = idx.search(qh[qi], k)
+    for qi in (0, 100, 255):   # (not the planted queries: a score of 1.0 is 3072 same-sign products, and the two
+        one = idx.search(qh[qi], k)   #  f32 summation orders differ by ~1e-5 there; ordinary scores are ~0.09)
         _same_up_to_near_ties(fs[qi], fr[qi], np.array([s for s, _ in one], dtype=np.float32),
                               np.array([r for _, r in one], dtype=np.int64), 4e-6)
     # host recomputation: the stored row (dequantised by the library) against the library's view of the query
