@@ -1,0 +1,579 @@
+// Batched score stage, MFMA-bound panels (256 queries x 256 corpus rows per workgroup):
+//     S[j][i] = sum_d M[i,d] * Q[j,d]      f16 (EB = 2) or e4m3 (EB = 1) operands, f32 accumulate
+// for BASELINE.json configs[2] (1M x 1536 f16, 1024 queries per call) and configs[4]
+// (10M x 3072 fp8, 256 queries per call).  Same arithmetic, k order, LDS image, swizzle and
+// epilogue as gemm_tiled_kernel<256, FUSE, EB, 256> (gemm_tiled.h) -- results are bit-identical --
+// but a different main loop.  The reference's nearest analogue is np.dot(M, M.T)
+// (src/svs/kb.py:1651); a query batch is a loop of np.dot(M, q) (src/svs/kb.py:1623).
+//
+// Why a second kernel: gemm_tiled's loop is "wait, barrier, issue the whole next k-step's LDS-DMA,
+// read fragments, 64 MFMAs" -- all eight waves issue DMA, then all read LDS, then all multiply,
+// and the matrix pipe idles through the first two (k-step 4,200 cycles for 2,048 of MFMA,
+// DESIGN.md).  Here a 128-byte k-tile is cut into FOUR phases, each multiplying one quadrant
+// (64 rows x 32 queries) of the wave's 128 x 64 tile: 4-12 ds_read_b128 + one half-tile of LDS-DMA
+// (2 instructions per wave) + 16 MFMAs (8 for fp8), between two raw s_barriers.  Waves 4-7 run
+// ONE BARRIER BEHIND waves 0-3 -- each SIMD hosts one wave of either group -- so in every
+// barrier interval one group multiplies while the other reads and stages: the matrix pipe
+// always has a wave to serve (cdna_hip_programming.md 5.5 T3/T4/T5).
+//
+// Data movement.  LDS = 8 slots of 16 KiB, a slot = one HALF-TILE = 128 rows x 128 bytes:
+//   B0 / B1: queries  wc * 64 + {0..31} / {32..63}   of the four wave columns wc
+//   A0 / A1: rows     wr * 128 + {0..63} / {64..127} of the two wave rows wr
+// i.e. exactly what phase 0 (B0, A0), phase 1 (B1) and phase 2 (A1) read; phase 3 reads nothing
+// (B0 is still in registers).  The stream of half-tiles B0 A0 B1 A1 | B0 A0 B1 A1 | ... runs
+// SEVEN half-tiles ahead of the phase that consumes it -- across k-tiles and across output tiles:
+// the kernel is persistent (one workgroup per CU walks its list of output tiles) and the stream
+// simply continues into the next tile, so its first loads are in flight before this tile's
+// epilogue starts.  Slot of half-tile H is H mod 8.
+//   RAW: phase P issues half-tile P + 7, then waits vmcnt(10) -- all but the 5 youngest
+//        half-tiles, i.e. everything up to P + 2, which is what phase P + 1 reads -- BEFORE its first
+//        barrier; the reads come one phase later, after both groups have passed a barrier behind
+//        that wait (LDS-DMA is ordered for a reader only by the issuers' vmcnt + a barrier).
+//   WAR: half-tile P + 7 overwrites P - 1, whose last read was two phases ago -- except B0 of the
+//        current k-tile (read in phase 0, overwritten in phase 1): phase 0 therefore issues its
+//        four B reads first and retires them with lgkmcnt(8) before its first barrier.
+// The DMA is `buffer_load_dwordx4 ... offen lds`: a per-tile descriptor (scalar) + a per-lane byte
+// offset fixed for the whole kernel + the k offset as scalar soffset -- no address arithmetic per
+// issue, and rows past n are dropped by the descriptor's range check (never read).  With no next
+// tile the descriptor has zero records: the instructions still issue (every wave keeps the same
+// vmcnt bookkeeping) and move nothing.  The XOR bank swizzle sits on the source side, as in
+// gemm_tiled.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gemm_tiled.h"
+
+namespace svs {
+
+constexpr int PG_TILE = 256;              // rows and queries per output tile
+constexpr int PG_SLOT = 1024;             // u32x4 per slot (16 KiB)
+constexpr int PG_LDS_BYTES = 8 * PG_SLOT * 16;
+constexpr int PG_THREADS = 512;
+
+#ifndef PG_VMCNT
+#define PG_VMCNT 10
+#endif
+
+#ifdef PG_CLOCKS   // tools/gemm_phased_bench.hip only: shader cycles and 100 MHz ticks a workgroup spent in the kernel
+__device__ unsigned long long* pg_clock_buf;
+#define PG_CLOCK_STAMP(slot)                                                                   \
+  do {                                                                                         \
+    if (threadIdx.x == 0) {                                                                    \
+      pg_clock_buf[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime();                    \
+      pg_clock_buf[blockIdx.x * 8 + 2 + (slot)] = __builtin_amdgcn_s_memrealtime();            \
+    }                                                                                          \
+  } while (0)
+#define PG_LOOP_CLOCK(var) do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory"); } while (0)
+#else
+#define PG_CLOCK_STAMP(slot) do { } while (0)
+#define PG_LOOP_CLOCK(var) do { } while (0)
+#endif
+
+#ifdef PG_TRACE   // tools/gemm_phased_bench.hip only: s_memtime stamps of 16 phases of one workgroup's third tile,
+// kept in LDS behind the ring and copied out at the end.  Slots per phase: 0 = after the phase's loads and
+// waits (before barrier 1), 1 = fragments in (after barrier 1), 2 = MFMAs issued (before barrier 2),
+// 3 = after barrier 2.  (Each stamp waits lgkmcnt(0): the one before barrier 1 also waits for the
+// phase's own fragment reads, which the untraced kernel leaves in flight across the barrier.)
+__device__ unsigned long long* pg_trace_buf;
+constexpr int PG_TRACE_KT0 = 4, PG_TRACE_KTS = 4, PG_TRACE_TILE = 2, PG_TRACE_BLOCK = 37;
+#define PG_STAMP(PH, SLOT)                                                                                  \
+  do {                                                                                                      \
+    if (tracing && kt >= PG_TRACE_KT0 && kt < PG_TRACE_KT0 + PG_TRACE_KTS) {                                \
+      unsigned long long t_;                                                                                \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                         \
+      if (lane == 0)                                                                                        \
+        *(volatile unsigned long long*)((char*)pg_lds + PG_LDS_TOTAL + ((wave * PG_TRACE_KTS * 4 + (kt - PG_TRACE_KT0) * 4 + (PH)) * 4 + (SLOT)) * 8) = t_; \
+    }                                                                                                       \
+  } while (0)
+#else
+#define PG_STAMP(PH, SLOT) do { } while (0)
+#endif
+
+// output tile `id` -> (row tile, query tile): the gy query tiles of a row tile get ids that are
+// equal mod 8 and adjacent in time, so they run on ONE XCD together (workgroups are dealt
+// round-robin over the XCDs) and the corpus tile comes from HBM once, from that L2 afterwards.
+__device__ __forceinline__ void pg_tile_of(int id, int gx, int gy, int* bx, int* by) {
+  const int full = (gx >> 3) << 3;
+  if (id < full * gy) {
+    const int grp = id / (8 * gy), within = id - grp * 8 * gy;
+    *bx = grp * 8 + (within & 7);
+    *by = within >> 3;
+  } else {
+    const int rem = gx - full, t = id - full * gy;
+    *bx = full + t % rem;
+    *by = t / rem;
+  }
+}
+
+struct PgTile {
+  __amdgpu_buffer_rsrc_t a, b;   // corpus rows / query rows of the tile
+  int64_t row0;
+  int q0;
+};
+
+// Fragment reads: inline asm with base + immediate offset.  Left to itself hipcc hoists all 48
+// fragment addresses of the two k-tile bodies out of the loop as separate VGPRs and spills
+// accumulators to pay for them (and every reload of a spilled address waits vmcnt(0), which
+// drains the LDS-DMA pipeline).  adr[half][h]: the lane's byte address in slot 0 / slot 4 (a
+// ds_read's immediate reaches 64 KiB, so one base per half of the 128 KiB).
+#define PG_DS_READ(dst, base, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(imm))
+template <int SLOT>
+__device__ __forceinline__ void pg_read_a(u32x4 (&fa)[4][2], const unsigned (&adr)[2][2]) {
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) PG_DS_READ(fa[mt][h], adr[SLOT >> 2][h], (SLOT & 3) * 16384 + mt * 2048);
+}
+template <int SLOT>
+__device__ __forceinline__ void pg_read_b(u32x4 (&fb)[2][2], const unsigned (&adr)[2][2]) {
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) PG_DS_READ(fb[nt][h], adr[SLOT >> 2][h], (SLOT & 3) * 16384 + nt * 2048);
+}
+#undef PG_DS_READ
+// "the fragments are in": the wait names every register the asm reads filled, so that nothing
+// that uses them can be scheduled in front of it (cdna_hip_programming.md 5.7, form (ii))
+__device__ __forceinline__ void pg_landed_a(u32x4 (&fa)[4][2]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[2][0]), "+v"(fa[2][1]),
+                 "+v"(fa[3][0]), "+v"(fa[3][1])::"memory");
+}
+__device__ __forceinline__ void pg_landed_b(u32x4 (&fb)[2][2]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[1][0]), "+v"(fb[1][1])::"memory");
+}
+
+// ---- side region of the LDS, behind the 128 KiB ring (fused top-k and fp8 scales) ------------
+// Per output tile the epilogue needs 256 thresholds (fused top-k), and for fp8 256 row scales and
+// 256 query scales.  An ordinary global load in the epilogue would make hipcc wait vmcnt(0) -- it
+// cannot count past LDS-DMA in flight -- i.e. drain the seven half-tiles prefetched for the next
+// tile, and then sit out the load's own latency; four returning global atomics per lane (one per
+// query column) did the same, one round trip each: together a quarter of the kernel's time.
+// So: the side data arrives by LDS-DMA too (issued before the tile's k loop, landed long before its
+// epilogue), and the epilogue PARKS its surviving candidates in LDS -- each wave in its own eighth
+// of the lot, slots from a wave-uniform counter and the lanes' ranks in the compare mask: no
+// atomics, no waits; they are flushed to the global candidate lists during the NEXT tile's k loop, in two steps
+// eight phases apart: returning global atomics issued by inline asm (hipcc inserts no wait for
+// them), their slots consumed after the loop's own counted waits have long covered them.
+// Two copies of everything, indexed by the tile's parity.
+#ifdef PG_TRACE
+constexpr int PG_PARK = 512;      // (trace builds keep their stamps behind the side region)
+#else
+constexpr int PG_PARK = 1024;     // candidates a workgroup can park per tile (~420 expected at k = 100, prefix n / 64)
+#endif
+constexpr int PG_SIDE = PG_LDS_BYTES;                   // byte offsets
+constexpr int PG_SIDE_THR = PG_SIDE;                    // f32 [2][256]
+constexpr int PG_SIDE_RS = PG_SIDE_THR + 2048;          // f32 [2][256] row scales (fp8)
+constexpr int PG_SIDE_QS = PG_SIDE_RS + 2048;           // f32 [2][256] query scales (fp8)
+constexpr int PG_SIDE_CNT = PG_SIDE_QS + 2048;          // u32 [2][8]: candidates parked by each wave
+constexpr int PG_SIDE_KEY = PG_SIDE_CNT + 64;           // u64 [2][PG_PARK]: wave w owns entries [w * PG_PARK / 8, ..)
+constexpr int PG_SIDE_QID = PG_SIDE_KEY + 2 * PG_PARK * 8;   // u32 [2][PG_PARK]
+constexpr int PG_LDS_TOTAL = PG_SIDE_QID + 2 * PG_PARK * 4;  // 161,808 bytes of the 163,840
+constexpr int PG_FLUSH_KT = 2, PG_MIN_KT = 6;   // the flush brackets k-tiles 2 and 3 of the next tile
+
+// LDS accesses of the epilogue / flush: inline asm, so that hipcc neither orders them against the
+// LDS-DMA in flight (with a vmcnt(0)) nor counts them
+__device__ __forceinline__ float pg_lds_read_f32(unsigned adr) {
+  float v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(adr) : "memory");
+  return v;
+}
+__device__ __forceinline__ uint32_t pg_lds_read_u32(unsigned adr) {
+  uint32_t v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(adr) : "memory");
+  return v;
+}
+__device__ __forceinline__ uint64_t pg_lds_read_u64(unsigned adr) {
+  uint64_t v;
+  asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(adr) : "memory");
+  return v;
+}
+__device__ __forceinline__ uint32_t pg_lds_add_rtn(unsigned adr, uint32_t x) {
+  uint32_t v;
+  asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(adr), "v"(x) : "memory");
+  return v;
+}
+__device__ __forceinline__ void pg_lds_write_u64(unsigned adr, uint64_t x) { asm volatile("ds_write_b64 %0, %1" ::"v"(adr), "v"(x) : "memory"); }
+__device__ __forceinline__ void pg_lds_write_u32(unsigned adr, uint32_t x) { asm volatile("ds_write_b32 %0, %1" ::"v"(adr), "v"(x) : "memory"); }
+
+// EXP != 0: timing-only ablations for tools/gemm_phased_bench.hip (results are wrong): 1 no LDS-DMA
+// in the main loop, 2 no fragment reads, 3 no MFMAs, 7 no stagger (all waves in the same phase),
+// 14 no epilogue.
+template <bool FUSE, int EB, int EXP = 0>
+__global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
+    const uint8_t* __restrict__ M, const uint8_t* __restrict__ Q, float* __restrict__ scores,
+    int64_t n, int ldb, int64_t sstride, int nq, int gx, int gy, uint32_t* __restrict__ fstate_words, int fstate_stride,
+    uint64_t* __restrict__ fcand, uint32_t fcap, const float* __restrict__ fthr, int fthr_stride,
+    const float* __restrict__ rscale, const float* __restrict__ qscale) {
+  static_assert(EB == 1 || EB == 2, "f16 or fp8 operands");
+  extern __shared__ u32x4 pg_lds[];
+  PG_CLOCK_STAMP(0);
+  constexpr int MT = 8, NT = 4;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int KT = ldb / TG_BKB;                       // k-tiles per output tile (even, >= PG_MIN_KT: checked by the host)
+  const int G = gridDim.x, total = gx * gy;
+  const int my_tiles = (total - (int)blockIdx.x + G - 1) / G;
+
+  // ---- per-lane constants of the staging side: byte offset of the lane's 16 bytes inside a tile
+  int voffA[2][2], voffB[2][2];                      // [half][instruction]
+  {
+    const int r_in = lane >> 3, pc = lane & 7;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int li = 8 * (wave + 8 * jj) + r_in;     // row of the half-tile image this lane fills
+      const int ch = (pc ^ tg_swz(li)) * 16;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        voffA[h][jj] = ((li >> 6) * 128 + h * 64 + (li & 63)) * ldb + ch;
+        voffB[h][jj] = ((li >> 5) * 64 + h * 32 + (li & 31)) * ldb + ch;
+      }
+    }
+  }
+  // ---- ... and of the reading side: LDS byte address of the lane's 16 bytes in slot 0 / slot 4
+  // (pg_read_a / pg_read_b)
+  unsigned adrA[2][2], adrB[2][2];                   // [LDS half][k half h]
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    adrA[0][h] = (unsigned)(((wr * 64 + r16) * 8 + ((4 * h + g) ^ tg_swz(r16))) * 16);
+    adrB[0][h] = (unsigned)(((wc * 32 + r16) * 8 + ((4 * h + g) ^ tg_swz(r16))) * 16);
+    adrA[1][h] = adrA[0][h] + 65536u;
+    adrB[1][h] = adrB[0][h] + 65536u;
+  }
+
+  auto tile_desc = [&](int j) {
+    PgTile t;
+    if (j < my_tiles) {
+      int bx, by;
+      pg_tile_of((int)blockIdx.x + j * G, gx, gy, &bx, &by);
+      t.row0 = (int64_t)bx * PG_TILE;
+      t.q0 = by * PG_TILE;
+      const int64_t live = n - t.row0 < PG_TILE ? n - t.row0 : PG_TILE;
+      t.a = __builtin_amdgcn_make_buffer_rsrc((void*)(M + t.row0 * ldb), 0, (int)(live * ldb), 0x00020000);
+      t.b = __builtin_amdgcn_make_buffer_rsrc((void*)(Q + (int64_t)t.q0 * ldb), 0, PG_TILE * ldb, 0x00020000);
+    } else {   // no such tile: zero records, every load through it is dropped
+      t.row0 = 0;
+      t.q0 = 0;
+      t.a = __builtin_amdgcn_make_buffer_rsrc((void*)M, 0, 0, 0x00020000);
+      t.b = __builtin_amdgcn_make_buffer_rsrc((void*)Q, 0, 0, 0x00020000);
+    }
+    return t;
+  };
+  PgTile cur = tile_desc(0), nxt = tile_desc(1);
+
+  // kind: 0 = B0, 1 = A0, 2 = B1, 3 = A1.  NEXT: the half-tile belongs to the next output tile
+  // (a compile-time fact: only the last two k-tiles of a tile stage across the seam).
+  auto stage = [&](auto KIND, auto SLOT, auto NEXT, int kt) {
+    constexpr int kind = decltype(KIND)::value, slot = decltype(SLOT)::value;
+    constexpr bool next = decltype(NEXT)::value != 0;
+    const int soff = kt * TG_BKB;
+    const __amdgpu_buffer_rsrc_t rs = (kind & 1) ? (next ? nxt.a : cur.a) : (next ? nxt.b : cur.b);
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int vo = (kind & 1) ? voffA[kind >> 1][jj] : voffB[kind >> 1][jj];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(pg_lds + slot * PG_SLOT + (wave + 8 * jj) * 64),
+                                               16, vo, soff, 0, 0);
+    }
+  };
+  // side data of tile `t` into copy `par`: every wave issues the same instructions (waves 4-7
+  // repeat waves 0-3: same bytes to the same place), 256 bytes each
+  auto stage_side = [&](const PgTile& t, int par) {
+    const int col = (wave & 3) * 64 + lane;
+    char* side = (char*)pg_lds;
+    if constexpr (FUSE) {
+      const int live = nq - t.q0 < PG_TILE ? nq - t.q0 : PG_TILE;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(fthr + (int64_t)t.q0 * fthr_stride), 0,
+                                                                          live * fthr_stride * 4, 0x00020000);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(side + PG_SIDE_THR + par * 1024 + (wave & 3) * 256),
+                                               4, col * fthr_stride * 4, 0, 0, 0);
+    }
+    if constexpr (EB == 1) {
+      const int64_t lrows = n - t.row0 < PG_TILE ? n - t.row0 : PG_TILE;
+      const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(rscale + t.row0), 0, (int)lrows * 4, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)(qscale + t.q0), 0, PG_TILE * 4, 0x00020000);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rr, (__attribute__((address_space(3))) void*)(side + PG_SIDE_RS + par * 1024 + (wave & 3) * 256), 4, col * 4, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (__attribute__((address_space(3))) void*)(side + PG_SIDE_QS + par * 1024 + (wave & 3) * 256), 4, col * 4, 0, 0, 0);
+    }
+  };
+
+  f32x4_t acc[MT][NT];
+  u32x4 fa[4][2], fb0[2][2], fb1[2][2];
+  if constexpr (EXP == 2) {   // (ablation without fragment reads: defined operands)
+    const u32x4 c = {0x3c003c00u + (uint32_t)lane, 0x3c003c00u, 0x38003800u, 0x3c003c00u};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[i][0] = fa[i][1] = c;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) fb0[i][0] = fb0[i][1] = fb1[i][0] = fb1[i][1] = c;
+  }
+  // one quadrant: rows 64 i .. 64 i + 63, queries 32 j .. 32 j + 31 of the wave tile
+  auto mma = [&](auto I, auto J, const u32x4 (&fb)[2][2]) {
+    constexpr int i = decltype(I)::value, j = decltype(J)::value;
+    if constexpr (EB == 2) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+            acc[i * 4 + mt][j * 2 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                __builtin_bit_cast(h8, fa[mt][h]), __builtin_bit_cast(h8, fb[nt][h]), acc[i * 4 + mt][j * 2 + nt], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const u32x4 al = fa[mt][0], ah = fa[mt][1];
+        const i32x8 x = {(int)al.x, (int)al.y, (int)al.z, (int)al.w, (int)ah.x, (int)ah.y, (int)ah.z, (int)ah.w};
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const u32x4 bl = fb[nt][0], bh = fb[nt][1];
+          const i32x8 y = {(int)bl.x, (int)bl.y, (int)bl.z, (int)bl.w, (int)bh.x, (int)bh.y, (int)bh.z, (int)bh.w};
+          acc[i * 4 + mt][j * 2 + nt] =
+              __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(x, y, acc[i * 4 + mt][j * 2 + nt], 0, 0, 0, 0, 0, 0);
+        }
+      }
+    }
+  };
+#define PG_C(v) std::integral_constant<int, (v)>{}
+  constexpr bool kStage = EXP != 1, kRead = EXP != 2, kMma = EXP != 3;
+  // what follows the loads of a phase: [retire the B reads] wait for the NEXT phase's data, barrier,
+  // fragments in, 16 MFMAs at raised priority (keeps hipcc from moving them over the barriers), barrier
+#define PG_SYNC_AND_MMA(PH, I, J, FB, LGKM8, LAND)                          \
+  do {                                                                      \
+    if (LGKM8 && kRead) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");  \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PG_VMCNT) : "memory");         \
+    PG_STAMP(PH, 0);                                                        \
+    __builtin_amdgcn_s_barrier();                                           \
+    if constexpr (kRead) { LAND; }                                          \
+    PG_STAMP(PH, 1);                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                      \
+    __builtin_amdgcn_s_setprio(1);                                          \
+    if constexpr (kMma) mma(PG_C(I), PG_C(J), FB);                          \
+    __builtin_amdgcn_s_setprio(0);                                          \
+    __builtin_amdgcn_sched_barrier(0);                                      \
+    PG_STAMP(PH, 2);                                                        \
+    __builtin_amdgcn_s_barrier();                                           \
+    PG_STAMP(PH, 3);                                                        \
+  } while (0)
+
+  // k-tile `kt` of the current output tile; PAR = parity of the k-tile in the stream (its slots
+  // are 4 PAR + kind, the other parity's are the ones being refilled).  TAIL: 0 = anywhere but the
+  // tile's last two k-tiles, 1 / 2 = the last but one / the last: their prefetch crosses into the
+  // next output tile (its k-tiles 0 and 1), through the next tile's descriptors.
+#ifdef PG_TRACE
+  bool tracing = false;
+#endif
+  auto ktile = [&](auto PAR, auto TAIL, int kt) {
+    constexpr int par = decltype(PAR)::value, tail = decltype(TAIL)::value;
+    constexpr int mine = 4 * par, other = 4 * (par ^ 1);
+    // half-tile staged in phase 0 is of k-tile kt + 1, in phases 1-3 of k-tile kt + 2
+    constexpr bool n1 = tail == 2, n2 = tail != 0;
+    const int k1 = tail == 2 ? 0 : kt + 1, k2 = tail == 0 ? kt + 2 : tail - 1;
+    // phase 0: B0, A0 in; quadrant (0, 0); stage A1 of the next k-tile
+    if constexpr (kRead) {
+      pg_read_b<mine + 0>(fb0, adrB);
+      __builtin_amdgcn_sched_barrier(0);
+      pg_read_a<mine + 1>(fa, adrA);
+    }
+    if constexpr (kStage) stage(PG_C(3), PG_C(other + 3), PG_C(n1), k1);
+    PG_SYNC_AND_MMA(0, 0, 0, fb0, true, (pg_landed_b(fb0), pg_landed_a(fa)));
+    // phase 1: B1 in; quadrant (0, 1); stage B0 of the k-tile after next (over this one's B0)
+    if constexpr (kRead) pg_read_b<mine + 2>(fb1, adrB);
+    if constexpr (kStage) stage(PG_C(0), PG_C(mine + 0), PG_C(n2), k2);
+    PG_SYNC_AND_MMA(1, 0, 1, fb1, false, pg_landed_b(fb1));
+    // phase 2: A1 in; quadrant (1, 1); stage A0
+    if constexpr (kRead) pg_read_a<mine + 3>(fa, adrA);
+    if constexpr (kStage) stage(PG_C(1), PG_C(mine + 1), PG_C(n2), k2);
+    PG_SYNC_AND_MMA(2, 1, 1, fb1, false, pg_landed_a(fa));
+    // phase 3: nothing to read; quadrant (1, 0); stage B1
+    if constexpr (kStage) stage(PG_C(2), PG_C(mine + 2), PG_C(n2), k2);
+    PG_SYNC_AND_MMA(3, 1, 0, fb0, false, (void)0);
+  };
+
+  // ---- flush of the candidates parked by the PREVIOUS tile (copy pp, queries pq0 ..): step A
+  // issues one returning global atomic per candidate (slot in the query's list), step B -- four
+  // k-tiles = 32 counted vmcnt waits later -- stores the keys
+  uint32_t fslot[2] = {0u, 0u};
+  int f_pp = 0, f_q0 = 0;     // wave-uniform
+  auto flush_a = [&]() {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int e = (int)threadIdx.x + r * PG_THREADS, w = e / (PG_PARK / 8), i = e % (PG_PARK / 8);
+      const uint32_t nw = pg_lds_read_u32(PG_SIDE_CNT + (f_pp * 8 + w) * 4);
+      if ((uint32_t)i < nw) {
+        const uint32_t q = pg_lds_read_u32(PG_SIDE_QID + (f_pp * PG_PARK + e) * 4);
+        uint32_t* p = fstate_words + (int64_t)(f_q0 + (int)q) * fstate_stride;
+        const uint32_t one = 1u;
+        asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(fslot[r]) : "v"(p), "v"(one) : "memory");
+      }
+    }
+  };
+  auto flush_b = [&](bool waited) {
+    if (!waited) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(fslot[0]), "+v"(fslot[1]) : "n"(PG_VMCNT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(fslot[0]), "+v"(fslot[1])::"memory");
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int e = (int)threadIdx.x + r * PG_THREADS, w = e / (PG_PARK / 8), i = e % (PG_PARK / 8);
+      const uint32_t nw = pg_lds_read_u32(PG_SIDE_CNT + (f_pp * 8 + w) * 4);
+      if ((uint32_t)i < nw && fslot[r] < fcap) {
+        const uint32_t q = pg_lds_read_u32(PG_SIDE_QID + (f_pp * PG_PARK + e) * 4);
+        const uint64_t sr = pg_lds_read_u64(PG_SIDE_KEY + (f_pp * PG_PARK + e) * 8);   // (score bits, row)
+        fcand[(int64_t)(f_q0 + (int)q) * fcap + fslot[r]] =
+            ((uint64_t)score_key(__builtin_bit_cast(float, (uint32_t)(sr >> 32))) << 32) | (uint32_t)sr;
+      }
+    }
+  };
+
+  // ---- epilogue of one tile: scales (fp8), then scores out (materialised) or candidates parked
+  auto epilogue = [&](const PgTile& t, int par) {
+    const int wrow = wr * 128, wq = wc * 64;
+    if constexpr (!FUSE) {
+      // (rows / queries past the ends are not stored; fp8 scales are applied by tg_epilogue's own loads: this
+      //  path is the prefix pass and set_variant(6), not the hot one)
+      tg_epilogue<false, EB, MT, NT, PG_TILE>(acc, t.row0, t.q0, wrow, wq, lane, n, nq, scores, sstride, fstate_words, fstate_stride,
+                                              fcand, fcap, fthr, fthr_stride, rscale, qscale);
+    } else {
+      // One pass over the wave's 32 x 4 score registers.  Per register: one compare (its lane mask
+      // lands in scalar registers), one scalar test; only if some lane survives (a third of the
+      // time at k = 100 over 1M rows) do those lanes compute their slot -- wave counter + rank inside
+      // the mask -- and write (key, query) into the wave's eighth of the parking lot.  A wave that
+      // overfills its eighth gives the fused path up for the queries concerned: it raises their
+      // candidate counts past any capacity (a fire-and-forget atomic OR), select_final marks them,
+      // and the host re-runs them through the materialised path -- exact, just not fast (rows
+      // ordered by similarity to a query, or a query made of NaNs: every score survives).
+      const int lr0 = wrow + 4 * g;                                        // the lane's first row inside the tile
+      const int lim = (int)(n - t.row0 < PG_TILE ? n - t.row0 : PG_TILE);  // live rows of this tile
+      constexpr int WCAP = PG_PARK / 8;
+      const unsigned kadr = PG_SIDE_KEY + (par * PG_PARK + wave * WCAP) * 8, qadr = PG_SIDE_QID + (par * PG_PARK + wave * WCAP) * 4;
+      const uint32_t row_lo = (uint32_t)(t.row0 + lr0);
+      int wcount = 0;   // wave-uniform
+      auto pass = [&](auto FULL) {
+        constexpr bool full = decltype(FULL)::value;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int ql = wq + j * 16 + r16;
+          const float thr = pg_lds_read_f32(PG_SIDE_THR + par * 1024 + ql * 4);
+          const unsigned long long qokm = __ballot(t.q0 + ql < nq);
+          float qs = 1.f;
+          if constexpr (EB == 1) qs = pg_lds_read_f32(PG_SIDE_QS + par * 1024 + ql * 4);
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float v = acc[i][j][r];
+              if constexpr (EB == 1) v *= qs * pg_lds_read_f32(PG_SIDE_RS + par * 1024 + (lr0 + i * 16 + r) * 4);
+              // lanes whose score is not below the threshold (unordered-or-greater-equal: a NaN passes), as a scalar mask
+              unsigned long long mask = __builtin_amdgcn_fcmpf(v, thr, 11 /* FCMP_UGE */) & qokm;
+              if constexpr (!full) mask &= __ballot(lr0 + i * 16 + r < lim);
+              if (__builtin_expect(mask != 0, 0)) {   // (unlikely: keeps the no-survivor path free of taken branches)
+                const bool hit = ((mask >> lane) & 1ull) != 0;
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                if (hit) {
+                  const int slot = wcount + rank;
+                  if (slot < WCAP) {   // (score bits, row): the order-preserving key is made at flush time
+                    pg_lds_write_u64(kadr + slot * 8, ((uint64_t)__builtin_bit_cast(uint32_t, v) << 32) | (row_lo + (uint32_t)(i * 16 + r)));
+                    pg_lds_write_u32(qadr + slot * 4, (uint32_t)ql);
+                  } else {
+                    __hip_atomic_fetch_or(fstate_words + (int64_t)(t.q0 + ql) * fstate_stride, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  }
+                }
+                wcount += __builtin_popcountll(mask);
+              }
+            }
+        }
+      };
+      if (lim == PG_TILE) pass(std::true_type{});
+      else pass(std::false_type{});
+      if (lane == 0) pg_lds_write_u32(PG_SIDE_CNT + (par * 8 + wave) * 4, (uint32_t)(wcount < WCAP ? wcount : WCAP));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // parked entries written before this wave's next barrier
+    }
+  };
+
+  // ---- prologue: half-tiles 0 .. 6 (k-tile 0 whole, B0 A0 B1 of k-tile 1), wait for the first
+  // two, one barrier for everybody, then waves 4-7 drop one barrier behind
+  stage(PG_C(0), PG_C(0), PG_C(0), 0);
+  stage(PG_C(1), PG_C(1), PG_C(0), 0);
+  stage(PG_C(2), PG_C(2), PG_C(0), 0);
+  stage(PG_C(3), PG_C(3), PG_C(0), 0);
+  stage(PG_C(0), PG_C(4), PG_C(0), 1);
+  stage(PG_C(1), PG_C(5), PG_C(0), 1);
+  stage(PG_C(2), PG_C(6), PG_C(0), 1);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PG_VMCNT) : "memory");
+  __builtin_amdgcn_s_barrier();
+  const bool behind = EXP == 7 ? false : wr == 1;
+  if (behind) __builtin_amdgcn_s_barrier();
+
+  // (KT is even -- the host checks it -- so a tile always starts on slot parity 0.  A run-time
+  // parity, `if (par) ktile<1> else ktile<0>`, made hipcc spill ~190 registers: it gave up
+  // keeping the accumulators in place across the join of the two bodies.)
+  unsigned long long loop_t0 = 0, loop_t1 = 0, loop_cycles = 0;   // (PG_CLOCKS builds: cycles inside the k loops)
+  for (int T = 0; T < my_tiles; ++T) {
+#ifdef PG_TRACE
+    tracing = blockIdx.x == PG_TRACE_BLOCK && T == PG_TRACE_TILE;
+#endif
+    const int tp = T & 1;
+    if constexpr (FUSE) stage_side(cur, tp);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    PG_LOOP_CLOCK(loop_t0);
+    for (int kt = 0; kt < KT - 2; kt += 2) {
+      // the previous tile's candidates: atomics out before this pair of k-tiles, slots used after it
+      // (eight phases = sixteen younger DMA instructions later: every counted wait since covers them);
+      // the returned slots live in registers only across this straight-line stretch
+      const bool flush = FUSE && T > 0 && kt == PG_FLUSH_KT;
+      if (flush) flush_a();
+      ktile(PG_C(0), PG_C(0), kt);
+      ktile(PG_C(1), PG_C(0), kt + 1);
+      if (flush) flush_b(EXP == 1);
+    }
+    ktile(PG_C(0), PG_C(1), KT - 2);
+    ktile(PG_C(1), PG_C(2), KT - 1);
+    PG_LOOP_CLOCK(loop_t1);
+    loop_cycles += loop_t1 - loop_t0;
+    if constexpr (EXP == 14) {   // (ablation: no epilogue; the accumulators stay live)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(acc[i][j]));
+    } else {
+      // Both groups run their epilogues TOGETHER: waves 0-3 wait one barrier for waves 4-7's last
+      // quadrant, and afterwards waves 4-7 drop one barrier behind again.  (Left staggered, each
+      // group's epilogue ran while the other stood at a barrier: twice the epilogue per tile.)
+      if (!behind && EXP != 7) __builtin_amdgcn_s_barrier();
+      epilogue(cur, tp);
+      if (behind) __builtin_amdgcn_s_barrier();
+    }
+    f_pp = tp;
+    f_q0 = cur.q0;
+    cur = nxt;
+    nxt = tile_desc(T + 2);
+  }
+  // waves 0-3 owe the barrier waves 4-7 took after the last epilogue (EXP 14: at the start);
+  // nothing may still be landing in LDS
+  if (!behind && EXP != 7) __builtin_amdgcn_s_barrier();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (FUSE && EXP != 14) {   // the last tile's candidates: flushed in place
+    __builtin_amdgcn_s_barrier();      // every wave has parked
+    flush_a();
+    flush_b(true);
+  }
+  PG_CLOCK_STAMP(1);
+#ifdef PG_CLOCKS
+  if (threadIdx.x == 0) pg_clock_buf[blockIdx.x * 8 + 4] = loop_cycles;
+#endif
+#ifdef PG_TRACE
+  if (blockIdx.x == PG_TRACE_BLOCK) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 8 * PG_TRACE_KTS * 4 * 4; i += PG_THREADS)
+      pg_trace_buf[i] = *(volatile unsigned long long*)((char*)pg_lds + PG_LDS_TOTAL + i * 8);
+  }
+#endif
+#undef PG_SYNC_AND_MMA
+#undef PG_STAMP
+#undef PG_C
+}
+
+}  // namespace svs

@@ -80,6 +80,90 @@ __device__ __forceinline__ void fuse_offer(uint32_t* hdr, uint64_t* cand, uint32
   if (slot < cap) cand[slot] = ((uint64_t)score_key(v) << 32) | row;
 }
 
+// ---- epilogue shared by gemm_tiled_kernel and gemm_phased_kernel ------------------------
+// acc[i][j] = one 16 x 16 f32 tile of the wave: rows row0 + wrow + 16 i + 4 g + r (r = register),
+// query q0 + wq + 16 j + (lane & 15).  FUSE == false: scores [nq][sstride] are written.
+// FUSE == true: scores that reach fthr[query] are offered to the query's candidate list.
+// EB == 1: scores are first multiplied by rscale[row] * qscale[query] (fp8 dequantisation).
+template <bool FUSE, int EB, int MT, int NT, int BM>
+__device__ __forceinline__ void tg_epilogue(f32x4_t (&acc)[MT][NT], int64_t row0, int q0, int wrow, int wq, int lane,
+                                            int64_t n, int nq, float* __restrict__ scores, int64_t sstride,
+                                            uint32_t* __restrict__ fstate_words, int fstate_stride,
+                                            uint64_t* __restrict__ fcand, uint32_t fcap,
+                                            const float* __restrict__ fthr, int fthr_stride,
+                                            const float* __restrict__ rscale, const float* __restrict__ qscale) {
+  const int r16 = lane & 15, g = lane >> 4;
+  // fp8: the lane's MT * 4 row scales, fetched once (they are the same for every query tile)
+  f32x4_t rs[EB == 1 ? MT : 1];
+  if constexpr (EB == 1) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int64_t ob = row0 + wrow + i * 16 + 4 * g;
+      if (ob + 3 < n) rs[i] = *(const f32x4_t*)(rscale + ob);   // row tiles start on multiples of 4
+      else
+        for (int r = 0; r < 4; ++r) rs[i][r] = rscale[ob + r < n ? ob + r : n - 1];
+    }
+  }
+  // D layout: column (query) = lane & 15, rows 4 g + r of each 16-row tile
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int query = q0 + wq + j * 16 + r16;
+    if (query < nq) {
+      if constexpr (EB == 1) {   // per-row and per-query dequantisation scales
+        const float qs = qscale[query];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][j][r] *= rs[i][r] * qs;
+      }
+      if constexpr (FUSE) {
+        // A lane holds MT * 4 scores of ONE query here.  It counts its survivors first and
+        // claims all their slots with ONE atomic (a returning atomic per surviving score made
+        // each wave wait ~40 L2 round trips per tile: 24 of the 72 us a 256x256 tile took).
+        // Interior tiles (all but the last row tile) skip the row-bound checks.
+        const float thr = fthr[(int64_t)query * fthr_stride];
+        const int lr0 = wrow + 4 * g;                          // the lane's first row inside the tile
+        const int lim = (int)(n - row0 < BM ? n - row0 : BM);  // live rows of this tile
+        auto offer = [&](auto FULL) {
+          constexpr bool full = decltype(FULL)::value;
+          uint32_t cnt = 0;
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cnt += (!(acc[i][j][r] < thr) && (full || lr0 + i * 16 + r < lim)) ? 1u : 0u;
+          if (cnt) {
+            uint32_t slot = atomicAdd(fstate_words + (int64_t)query * fstate_stride, cnt);
+            uint64_t* cq = fcand + (int64_t)query * fcap;
+            const uint32_t row_lo = (uint32_t)(row0 + lr0);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float v = acc[i][j][r];
+                if (!(v < thr) && (full || lr0 + i * 16 + r < lim)) {
+                  if (slot < fcap) cq[slot] = ((uint64_t)score_key(v) << 32) | (row_lo + (uint32_t)(i * 16 + r));
+                  ++slot;
+                }
+              }
+          }
+        };
+        if (lim == BM) offer(std::true_type{});
+        else offer(std::false_type{});
+      } else {
+        float* o = scores + (int64_t)query * sstride;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int64_t ob = row0 + wrow + i * 16 + 4 * g;
+          if (ob + 3 < n) *(f32x4_t*)(o + ob) = acc[i][j];
+          else
+            for (int r = 0; r < 4; ++r)
+              if (ob + r < n) o[ob + r] = acc[i][j][r];
+        }
+      }
+    }
+  }
+}
+
 // Stage `rows` rows x 128 B starting at k-step `s` into `lds` (linear image),
 // rows [row0, row0+rows) of a row-major half matrix with stride ld; rows past
 // row_max are clamped (their products are never stored).  One wave instruction
@@ -309,75 +393,8 @@ __global__ __launch_bounds__(TG_WAVES * 64) void gemm_tiled_kernel(
   }
 
   TG_STAMP_BLOCK(2);
-  // fp8: the lane's MT * 4 row scales, fetched once (they are the same for every query tile)
-  f32x4_t rs[EB == 1 ? MT : 1];
-  if constexpr (EB == 1) {
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int64_t ob = row0 + wm * TM + i * 16 + 4 * g;
-      if (ob + 3 < n) rs[i] = *(const f32x4_t*)(rscale + ob);   // row tiles start on multiples of 4
-      else
-        for (int r = 0; r < 4; ++r) rs[i][r] = rscale[ob + r < n ? ob + r : n - 1];
-    }
-  }
-  // D layout: column (query) = lane & 15, rows 4 g + r of each 16-row tile
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int query = q0 + wn * TN + j * 16 + r16;
-    if (query < nq) {
-      if constexpr (EB == 1) {   // per-row and per-query dequantisation scales
-        const float qs = qscale[query];
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[i][j][r] *= rs[i][r] * qs;
-      }
-      if constexpr (FUSE) {
-        // A lane holds MT * 4 scores of ONE query here.  It counts its survivors first and
-        // claims all their slots with ONE atomic (a returning atomic per surviving score made
-        // each wave wait ~40 L2 round trips per tile: 24 of the 72 us a 256x256 tile took).
-        // Interior tiles (all but the last row tile) skip the row-bound checks.
-        const float thr = fthr[(int64_t)query * fthr_stride];
-        const int lr0 = wm * TM + 4 * g;                      // the lane's first row inside the tile
-        const int lim = (int)(n - row0 < BM ? n - row0 : BM);  // live rows of this tile
-        auto offer = [&](auto FULL) {
-          constexpr bool full = decltype(FULL)::value;
-          uint32_t cnt = 0;
-#pragma unroll
-          for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) cnt += (!(acc[i][j][r] < thr) && (full || lr0 + i * 16 + r < lim)) ? 1u : 0u;
-          if (cnt) {
-            uint32_t slot = atomicAdd(fstate_words + (int64_t)query * fstate_stride, cnt);
-            uint64_t* cq = fcand + (int64_t)query * fcap;
-            const uint32_t row_lo = (uint32_t)(row0 + lr0);
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const float v = acc[i][j][r];
-                if (!(v < thr) && (full || lr0 + i * 16 + r < lim)) {
-                  if (slot < fcap) cq[slot] = ((uint64_t)score_key(v) << 32) | (row_lo + (uint32_t)(i * 16 + r));
-                  ++slot;
-                }
-              }
-          }
-        };
-        if (lim == BM) offer(std::true_type{});
-        else offer(std::false_type{});
-      } else {
-        float* o = scores + (int64_t)query * sstride;
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          const int64_t ob = row0 + wm * TM + i * 16 + 4 * g;
-          if (ob + 3 < n) *(f32x4_t*)(o + ob) = acc[i][j];
-          else
-            for (int r = 0; r < 4; ++r)
-              if (ob + r < n) o[ob + r] = acc[i][j][r];
-        }
-      }
-    }
-  }
+  tg_epilogue<FUSE, EB, MT, NT, BM>(acc, row0, q0, wm * TM, wn * TN, lane, n, nq, scores, sstride, fstate_words, fstate_stride,
+                                    fcand, fcap, fthr, fthr_stride, rscale, qscale);
   TG_STAMP_BLOCK(3);
 }
 

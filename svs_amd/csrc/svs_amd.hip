@@ -19,6 +19,7 @@
 
 #include "fp8.h"
 #include "gemm_tiled.h"
+#include "gemm_phased.h"
 #include "gemm_q16.h"
 #include "gemv_unrolled.h"
 #include "gemv_f16.h"
@@ -572,10 +573,42 @@ int launch_tiled_bn(const svs_index* idx, Ctx* c, int64_t n_rows, int nq, float*
   return SVS_OK;
 }
 
+// 256 x 256 output tiles, persistent workgroups, four-phase k-tiles (gemm_phased.h)
+template <bool FUSE, int EB>
+int launch_phased(const svs_index* idx, Ctx* c, int64_t n_rows, int nq, float* scores, int64_t sstride,
+                  FuseLaunch fl, hipStream_t st) {
+  static std::once_flag once;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute((const void*)gemm_phased_kernel<FUSE, EB>, hipFuncAttributeMaxDynamicSharedMemorySize, PG_LDS_TOTAL);
+  });
+  const int gx = (int)((n_rows + PG_TILE - 1) / PG_TILE), gy = (nq + PG_TILE - 1) / PG_TILE;
+  const int64_t total = (int64_t)gx * gy;
+  const unsigned grid = (unsigned)std::min<int64_t>(total, idx->cu_count);   // one persistent workgroup per CU
+  const uint8_t* Q = EB == 2 ? (const uint8_t*)c->qh : (const uint8_t*)c->q8;
+  hipLaunchKernelGGL((gemm_phased_kernel<FUSE, EB>), dim3(grid), dim3(PG_THREADS), PG_LDS_TOTAL, st,
+                     (const uint8_t*)idx->rows, Q, scores, n_rows, (int)(idx->ld * EB), sstride, nq, gx, gy,
+                     fl.state, (int)SCR_WORDS, fl.cand, (uint32_t)CAND_CAP, fl.thr, fl.thr_stride,
+                     (const float*)idx->row_scales, (const float*)c->q8s);
+  return SVS_OK;
+}
+
+// the phased kernel's preconditions: an even number (>= 6) of 128-byte k-tiles per row, tile bytes
+// and tile counts inside 32-bit descriptors / ints
+bool phased_ok(const svs_index* idx, int64_t n_rows, int nq) {
+  const int64_t ldb = (int64_t)idx->ld * (int64_t)elem_bytes(idx);
+  return idx->variant.load() != 2 && idx->dtype == SVS_DTYPE_F16 && ldb % (2 * TG_BKB) == 0 && ldb >= PG_MIN_KT * TG_BKB && ldb <= (1 << 20) &&
+         ((n_rows + PG_TILE - 1) / PG_TILE) * ((nq + PG_TILE - 1) / PG_TILE) < (1ll << 30);
+}
+
 template <int EB>
 int launch_tiled_eb(const svs_index* idx, Ctx* c, int64_t n_rows, int nq, int bn, float* scores, int64_t sstride,
                     FuseLaunch fl, hipStream_t st) {
   const bool f = fl.state != nullptr;
+  if constexpr (EB != 4) {
+    if (bn == 256 && phased_ok(idx, n_rows, nq))
+      return f ? launch_phased<true, EB>(idx, c, n_rows, nq, scores, sstride, fl, st)
+               : launch_phased<false, EB>(idx, c, n_rows, nq, scores, sstride, fl, st);
+  }
   switch (bn) {
     case 32: return f ? launch_tiled_bn<32, true, EB>(idx, c, n_rows, nq, scores, sstride, fl, st) : launch_tiled_bn<32, false, EB>(idx, c, n_rows, nq, scores, sstride, fl, st);
     case 64:   // (256-row tiles measured 2-5 % slower here)

@@ -1,0 +1,62 @@
+"""GPU: the four-phase 256 x 256 MFMA kernel (svs_amd/csrc/gemm_phased.h; batches of more than 128
+queries over f16 / fp8 corpora -- BASELINE.json configs[2] and configs[4]) against
+  * the numpy oracle on the stored (rounded / quantised) corpus, and
+  * the round-1 kernel it replaces (gemm_tiled_kernel<256, ., ., 256>, kept behind
+    svs_index_set_variant(2)): same arithmetic in the same k order, so BIT-identical scores and rows.
+The second check is also the race screen for the LDS-DMA ring (reads are placed by the
+vmcnt / barrier counts; an early read shows up as a rare wrong tile): every shape is searched
+several times, and the repetitions must agree bit for bit."""
+import numpy as np
+import pytest
+
+from compare import assert_topk_parity
+from oracle import svs_oracle as oracle
+from synth import corpus_and_query
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype,n,d,nq,k", [
+    ("f16", 140000, 1536, 300, 100),   # fused top-k, two query tiles (one partial), last row tile partial
+    ("f16", 131072 + 77, 256, 129, 50),  # 4 k-tiles per row, one query tile with 127 padded queries
+    ("f16", 9000, 128, 256, 100),      # 2 k-tiles per row (the minimum), materialised scores (n < 131,072)
+    ("f16", 300, 1536, 200, 300),      # fewer rows than one tile, k == n
+    ("f16", 20000, 768, 1024, 10),     # 4 query tiles share every row tile
+    ("fp8", 140000, 3072, 256, 100),   # configs[4]'s row length
+    ("fp8", 10000, 256, 130, 20),      # 2 k-tiles per row
+    ("fp8", 135000, 1536, 513, 64),    # three query tiles, the last with one query
+])
+def test_phased_equals_round1_kernel_and_oracle(gpu, dtype, n, d, nq, k):
+    from svs_amd import DeviceIndex
+    m, qs = corpus_and_query("gaussian", 900 + n % 1000 + nq, n, d, nq)
+    idx = DeviceIndex(m, dtype=dtype)
+    s0, r0 = idx.search_batch(qs, k)
+    for rep in range(4):                 # race screen: repetitions agree bit for bit
+        s1, r1 = idx.search_batch(qs, k)
+        assert np.array_equal(r0, r1) and np.array_equal(s0, s1), f"run {rep} differs"
+    idx.set_variant(2)                   # the round-1 256 x 256 kernel
+    s2, r2 = idx.search_batch(qs, k)
+    idx.set_variant(0)
+    assert np.array_equal(r0, r2) and np.array_equal(s0, s2), "phased kernel != gemm_tiled kernel"
+    md = idx.stored_rows()
+    for qi in sorted({0, 1, nq // 2, 255 % nq, nq - 1}):
+        qd = idx.stored_query(qs[qi])
+        exp = oracle.cpu_search(md, qd, k)
+        assert_topk_parity(s0[qi], r0[qi], [s for s, _ in exp], [i for _, i in exp],
+                           oracle.cpu_scores_f64(md, qd), label=f"phased {dtype} {n}x{d} q{qi}")
+    idx.release()
+
+
+def test_phased_odd_ktile_count_falls_back(gpu):
+    """Rows with an odd number of 128-byte k-tiles (d = 192 halves = 3 tiles) are not the phased
+    kernel's: the tiled kernel serves them, results as the oracle's."""
+    from svs_amd import DeviceIndex
+    m, qs = corpus_and_query("gaussian", 5, 6000, 192, 200)
+    idx = DeviceIndex(m, dtype="f16")
+    s, r = idx.search_batch(qs, 20)
+    md = idx.stored_rows()
+    for qi in (0, 199):
+        qd = idx.stored_query(qs[qi])
+        exp = oracle.cpu_search(md, qd, 20)
+        assert_topk_parity(s[qi], r[qi], [x for x, _ in exp], [i for _, i in exp], oracle.cpu_scores_f64(md, qd), label="odd k-tiles")
+    idx.release()
