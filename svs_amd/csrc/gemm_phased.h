@@ -269,13 +269,17 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
   auto stage = [&](auto KIND, auto SLOT, auto NEXT, int kt) {
     constexpr int kind = decltype(KIND)::value, slot = decltype(SLOT)::value;
     constexpr bool next = decltype(NEXT)::value != 0;
-    const int soff = kt * TG_BKB;
+    const int soff = EXP == 21 ? 0 : kt * TG_BKB;   // (ablation 21: always the first k-tile: L2 hits)
     const __amdgpu_buffer_rsrc_t rs = (kind & 1) ? (next ? nxt.a : cur.a) : (next ? nxt.b : cur.b);
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
       const int vo = (kind & 1) ? voffA[kind >> 1][jj] : voffB[kind >> 1][jj];
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(pg_lds + slot * PG_SLOT + (wave + 8 * jj) * 64),
-                                               16, vo, soff, 0, 0);
+      if constexpr (EXP == 20 && (kind & 1))   // (ablation: corpus rows nontemporal)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(pg_lds + slot * PG_SLOT + (wave + 8 * jj) * 64),
+                                                 16, vo, soff, 0, 2);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(pg_lds + slot * PG_SLOT + (wave + 8 * jj) * 64),
+                                                 16, vo, soff, 0, 0);
     }
   };
   // side data of tile `t` into copy `par`: every wave issues the same instructions (waves 4-7
@@ -448,8 +452,8 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
       const unsigned kadr = PG_SIDE_KEY + (par * PG_PARK + wave * WCAP) * 8, qadr = PG_SIDE_QID + (par * PG_PARK + wave * WCAP) * 4;
       const uint32_t row_lo = (uint32_t)(t.row0 + lr0);
       int wcount = 0;   // wave-uniform
-      auto pass = [&](auto FULL) {
-        constexpr bool full = decltype(FULL)::value;
+      auto pass = [&](auto FULL, auto QALL) {
+        constexpr bool full = decltype(FULL)::value, qall = decltype(QALL)::value;   // whole tile inside the corpus / the batch
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           const int ql = wq + j * 16 + r16;
@@ -458,33 +462,43 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
           float qs = 1.f;
           if constexpr (EB == 1) qs = pg_lds_read_f32(PG_SIDE_QS + par * 1024 + ql * 4);
 #pragma unroll
-          for (int i = 0; i < MT; ++i)
+          for (int i = 0; i < MT; ++i) {
+            // the four compares of a tile first (their lane masks land in scalar registers: a
+            // compare -> scalar test -> branch chain per register costs ~60 cycles of latency each)
+            float v[4];
+            unsigned long long mask[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              float v = acc[i][j][r];
-              if constexpr (EB == 1) v *= qs * pg_lds_read_f32(PG_SIDE_RS + par * 1024 + (lr0 + i * 16 + r) * 4);
-              // lanes whose score is not below the threshold (unordered-or-greater-equal: a NaN passes), as a scalar mask
-              unsigned long long mask = __builtin_amdgcn_fcmpf(v, thr, 11 /* FCMP_UGE */) & qokm;
-              if constexpr (!full) mask &= __ballot(lr0 + i * 16 + r < lim);
-              if (__builtin_expect(mask != 0, 0)) {   // (unlikely: keeps the no-survivor path free of taken branches)
-                const bool hit = ((mask >> lane) & 1ull) != 0;
-                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+              v[r] = acc[i][j][r];
+              if constexpr (EB == 1) v[r] *= qs * pg_lds_read_f32(PG_SIDE_RS + par * 1024 + (lr0 + i * 16 + r) * 4);
+              // lanes whose score is not below the threshold (unordered-or-greater-equal: a NaN passes)
+              mask[r] = __builtin_amdgcn_fcmpf(v[r], thr, 11 /* FCMP_UGE */);
+              if constexpr (!qall) mask[r] &= qokm;
+              if constexpr (!full) mask[r] &= __ballot(lr0 + i * 16 + r < lim);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              if (__builtin_expect(mask[r] != 0, 0)) {   // (unlikely: keeps the no-survivor path free of taken branches)
+                const bool hit = ((mask[r] >> lane) & 1ull) != 0;
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask[r] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask[r], 0u));
                 if (hit) {
                   const int slot = wcount + rank;
                   if (slot < WCAP) {   // (score bits, row): the order-preserving key is made at flush time
-                    pg_lds_write_u64(kadr + slot * 8, ((uint64_t)__builtin_bit_cast(uint32_t, v) << 32) | (row_lo + (uint32_t)(i * 16 + r)));
+                    pg_lds_write_u64(kadr + slot * 8, ((uint64_t)__builtin_bit_cast(uint32_t, v[r]) << 32) | (row_lo + (uint32_t)(i * 16 + r)));
                     pg_lds_write_u32(qadr + slot * 4, (uint32_t)ql);
                   } else {
                     __hip_atomic_fetch_or(fstate_words + (int64_t)(t.q0 + ql) * fstate_stride, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                   }
                 }
-                wcount += __builtin_popcountll(mask);
+                wcount += __builtin_popcountll(mask[r]);
               }
             }
+          }
         }
       };
-      if (lim == PG_TILE) pass(std::true_type{});
-      else pass(std::false_type{});
+      // (interior tiles -- all but the last row tile and the last query tile -- test one compare per register)
+      if (lim == PG_TILE && t.q0 + PG_TILE <= nq) pass(std::true_type{}, std::true_type{});
+      else pass(std::false_type{}, std::false_type{});
       if (lane == 0) pg_lds_write_u32(PG_SIDE_CNT + (par * 8 + wave) * 4, (uint32_t)(wcount < WCAP ? wcount : WCAP));
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // parked entries written before this wave's next barrier
     }
@@ -508,6 +522,7 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
   // parity, `if (par) ktile<1> else ktile<0>`, made hipcc spill ~190 registers: it gave up
   // keeping the accumulators in place across the join of the two bodies.)
   unsigned long long loop_t0 = 0, loop_t1 = 0, loop_cycles = 0;   // (PG_CLOCKS builds: cycles inside the k loops)
+  unsigned long long epi_t0 = 0, epi_t1 = 0, epi_cycles = 0;      // (... and inside the epilogues)
   for (int T = 0; T < my_tiles; ++T) {
 #ifdef PG_TRACE
     tracing = blockIdx.x == PG_TRACE_BLOCK && T == PG_TRACE_TILE;
@@ -543,7 +558,10 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
       // quadrant, and afterwards waves 4-7 drop one barrier behind again.  (Left staggered, each
       // group's epilogue ran while the other stood at a barrier: twice the epilogue per tile.)
       if (!behind && EXP != 7) __builtin_amdgcn_s_barrier();
+      PG_LOOP_CLOCK(epi_t0);
       epilogue(cur, tp);
+      PG_LOOP_CLOCK(epi_t1);
+      epi_cycles += epi_t1 - epi_t0;
       if (behind) __builtin_amdgcn_s_barrier();
     }
     f_pp = tp;
@@ -563,6 +581,7 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
   PG_CLOCK_STAMP(1);
 #ifdef PG_CLOCKS
   if (threadIdx.x == 0) pg_clock_buf[blockIdx.x * 8 + 4] = loop_cycles;
+  if (threadIdx.x == 0) pg_clock_buf[blockIdx.x * 8 + 5] = epi_cycles;
 #endif
 #ifdef PG_TRACE
   if (blockIdx.x == PG_TRACE_BLOCK) {

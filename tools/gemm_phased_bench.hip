@@ -77,7 +77,8 @@ int run(int64_t n, int d, int nq, int rounds) {
   struct V { const char* name; Fn fn; };
   const V vs[] = {{"round-1 tiled 256x256", launch_tiled<EB>}, {"phased", launch_phased<EB, 0>}, {"phased, no LDS-DMA in loop", launch_phased<EB, 1>},
                   {"phased, no fragment reads", launch_phased<EB, 2>}, {"phased, no MFMA", launch_phased<EB, 3>},
-                  {"phased, no stagger", launch_phased<EB, 7>}, {"phased, no epilogue", launch_phased<EB, 14>}};
+                  {"phased, no stagger", launch_phased<EB, 7>}, {"phased, no epilogue", launch_phased<EB, 14>},
+                  {"phased, every DMA from the first k-tile (L2)", launch_phased<EB, 21>}};
   const int NVALL = sizeof(vs) / sizeof(vs[0]);
   const char* only = getenv("PGB_ONLY");          // e.g. PGB_ONLY=2 runs variant 2 alone (fault hunting)
   V sel[16]; int NV = 0;
@@ -99,19 +100,19 @@ int run(int64_t n, int d, int nq, int rounds) {
       float t; CK(hipEventElapsedTime(&t, e0, e1)); ms[v].push_back(t / 4);
     }
   // in-kernel clock of the phased variants: shader cycles / 100 MHz ticks, median over workgroups
-  std::vector<double> ghz(NV, 0.0), kcyc(NV, 0.0), lcyc(NV, 0.0);
+  std::vector<double> ghz(NV, 0.0), kcyc(NV, 0.0), lcyc(NV, 0.0), ecyc(NV, 0.0);
   for (int v = only ? 0 : 1; v < NV; ++v) {
     if (only && atoi(only) == 0) break;
     for (int i = 0; i < 3; ++i) vs[v].fn(a, cus);
     CK(hipDeviceSynchronize());
     std::vector<unsigned long long> hc(256 * 8); CK(hipMemcpy(hc.data(), cb, hc.size() * 8, hipMemcpyDeviceToHost));
-    std::vector<double> g, c, l;
+    std::vector<double> g, c, l, ep;
     for (int b = 0; b < cus && b < 256; ++b) {
       const double cyc = (double)(hc[b * 8 + 1] - hc[b * 8]), tick = (double)(hc[b * 8 + 3] - hc[b * 8 + 2]);
-      if (tick > 0) { g.push_back(cyc / tick * 0.1); c.push_back(cyc); l.push_back((double)hc[b * 8 + 4]); }
+      if (tick > 0) { g.push_back(cyc / tick * 0.1); c.push_back(cyc); l.push_back((double)hc[b * 8 + 4]); ep.push_back((double)hc[b * 8 + 5]); }
     }
-    std::sort(g.begin(), g.end()); std::sort(c.begin(), c.end()); std::sort(l.begin(), l.end());
-    if (!g.empty()) { ghz[v] = g[g.size() / 2]; kcyc[v] = c[c.size() / 2]; lcyc[v] = l[l.size() / 2]; }
+    std::sort(g.begin(), g.end()); std::sort(c.begin(), c.end()); std::sort(l.begin(), l.end()); std::sort(ep.begin(), ep.end());
+    if (!g.empty()) { ghz[v] = g[g.size() / 2]; kcyc[v] = c[c.size() / 2]; lcyc[v] = l[l.size() / 2]; ecyc[v] = ep[ep.size() / 2]; }
   }
   const double flop = 2.0 * n * d * nq;
   printf("EB=%d  %lld x %d, %d queries (%d CUs), per launch: median [min] of %d rounds of 4\n", EB, (long long)n, d, nq, cus, rounds);
@@ -119,8 +120,8 @@ int run(int64_t n, int d, int nq, int rounds) {
     std::sort(ms[v].begin(), ms[v].end());
     const float med = ms[v][ms[v].size() / 2], mn = ms[v][0];
     const double ktiles = (double)((n + 255) / 256) * ((nq + 255) / 256) / cus * (d * EB / 128);
-    printf("  %-44s %7.3f ms [%7.3f] %7.1f TFLOP/s  %.2f GHz, %5.0f cycles per k-tile (%5.0f inside the k loop)\n", vs[v].name, med, mn,
-           flop / (med * 1e-3) / 1e12, ghz[v], kcyc[v] / ktiles, lcyc[v] / ktiles);
+    printf("  %-44s %7.3f ms [%7.3f] %7.1f TFLOP/s  %.2f GHz, %5.0f cycles per k-tile (%5.0f inside the k loop), epilogue %6.0f cycles per tile\n", vs[v].name, med, mn,
+           flop / (med * 1e-3) / 1e12, ghz[v], kcyc[v] / ktiles, lcyc[v] / ktiles, ecyc[v] / (ktiles / (d * EB / 128)));
   }
   fflush(stdout);
   hipFree(a.M); hipFree(a.Q); hipFree(a.st); hipFree(a.cand); hipFree(a.thr); hipFree(a.rs);
