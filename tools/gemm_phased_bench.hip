@@ -77,8 +77,7 @@ int run(int64_t n, int d, int nq, int rounds) {
   struct V { const char* name; Fn fn; };
   const V vs[] = {{"round-1 tiled 256x256", launch_tiled<EB>}, {"phased", launch_phased<EB, 0>}, {"phased, no LDS-DMA in loop", launch_phased<EB, 1>},
                   {"phased, no fragment reads", launch_phased<EB, 2>}, {"phased, no MFMA", launch_phased<EB, 3>},
-                  {"phased, no stagger", launch_phased<EB, 7>}, {"phased, no epilogue", launch_phased<EB, 14>},
-                  {"phased, every DMA from the first k-tile (L2)", launch_phased<EB, 21>}};
+                  {"phased, no stagger", launch_phased<EB, 7>}, {"phased, no epilogue", launch_phased<EB, 14>}};
   const int NVALL = sizeof(vs) / sizeof(vs[0]);
   const char* only = getenv("PGB_ONLY");          // e.g. PGB_ONLY=2 runs variant 2 alone (fault hunting)
   V sel[16]; int NV = 0;
