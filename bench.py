@@ -33,6 +33,48 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md, chip-level parameters)
+MFMA_PEAK = {"f16": 2.5e15, "fp8": 5.0e15}  # dense FLOP/s (same table; never the 2:1-sparsity figures)
+KERNEL_NAME = {  # dominant kernel per dtype and batch shape (svs_amd/csrc)
+    ("f32", 1): "gemv_f32_oneshot_kernel (gemv_f32.h)", ("f16", 1): "gemv_f16_oneshot_kernel (gemv_f16.h)",
+    ("fp8", 1): "gemv_fp8_oneshot_kernel (fp8.h)", ("f32", 16): "gemm_q16r_kernel<FUSE, 4> (gemm_q16.h)",
+    ("f32", 256): "gemm_tiled_kernel<64, FUSE, 4> (gemm_tiled.h)", ("f16", 1024): "gemm_phased_kernel<FUSE, 2> (gemm_phased.h)",
+    ("fp8", 256): "gemm_tiled_kernel<256, FUSE, 1, 256> (gemm_tiled.h)",
+}
+
+
+def batched_config(torch, idx, name, n, d, dtype, nq, k, seed, reps):
+    """Secondary figure: one BASELINE.json batch configuration on an index already in HBM.  Kernel
+    time = HIP events around the dominant kernel launch inside the library (svs_timing_t.dominant_ms_sum)."""
+    dev = torch.device("cuda", idx.device)
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    q = torch.randn((nq, d), device=dev, dtype=torch.float32, generator=g)
+    q = (q / q.norm(dim=1, keepdim=True)).cpu().numpy()
+    for _ in range(3):
+        idx.search_batch(q, k)
+    idx.set_timing(True)
+    a = time.perf_counter()
+    for _ in range(reps):
+        idx.search_batch(q, k)
+    dt = time.perf_counter() - a
+    score_ms, select_ms, cnt = idx.get_timing()
+    dom_ms = idx.last_dominant_ms_sum / max(cnt, 1)
+    idx.set_timing(False)
+    esz = {"f32": 4, "f16": 2, "fp8": 1}[dtype]
+    flops = 2.0 * n * d * nq
+    bytes_ = float(n) * d * esz + (4.0 * n if dtype == "fp8" else 0.0)
+    pf = flops / (dom_ms * 1e-3)
+    out = {"workload": name, "queries_per_call": nq, "ms_per_call": dt / reps * 1e3, "value": nq * reps / dt, "unit": "queries/s",
+           "stage_ms": {"score": score_ms / max(cnt, 1), "select": select_ms / max(cnt, 1), "dominant_kernel": dom_ms},
+           "roofline": {"bound": "mfma", "kernel": KERNEL_NAME.get((dtype, nq), "batched GEMM"), "achieved": pf / 1e12,
+                        "peak": MFMA_PEAK[dtype] / 1e12, "unit": "TFLOP/s", "frac": pf / MFMA_PEAK[dtype],
+                        "algorithmic_flops_per_launch": flops, "avg_launch_ms": dom_ms, "launches_timed": cnt,
+                        "traffic": None},
+           "note": "host API (queries in, results out, synchronised); kernel time from HIP events inside the library"}
+    if dtype == "fp8":   # SURVEY 8(d) cfg5: mixed bound, both fractions
+        out["roofline_hbm"] = {"bound": "hbm", "achieved": bytes_ / (dom_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                               "frac": bytes_ / (dom_ms * 1e-3) / HBM_PEAK, "algorithmic_bytes_per_launch": bytes_}
+    return out
 
 
 def gen_rows(torch, dev, seed, lo, hi, d, block=62500):
@@ -73,6 +115,9 @@ def main():
                     help="N > 1: steps whose local top-k records share one RCCL all-gather")
     ap.add_argument("--batch", default="16,256",
                     help="queries per call of the secondary batched figures, comma separated (0: skip)")
+    ap.add_argument("--configs", default="2,4",
+                    help="BASELINE.json batch configs measured as secondary figures at N = 1 (2: 1M x 1536 f16 x 1024 "
+                         "queries; 4: 10M x 3072 fp8 x 256 queries; empty: skip)")
     ap.add_argument("--inflight", type=int, default=1,
                     help="searches kept in flight on separate HIP streams (2 lets the top-k "
                          "stage of query i overlap the score stage of query i+1)")
@@ -81,7 +126,7 @@ def main():
     import torch
     import torch.distributed as dist
     from svs_amd import DeviceIndex
-    from svs_amd.sharded import merge_topk, record_layout, shard_bounds, unpack_records
+    from svs_amd.sharded import ShardedIndex, shard_bounds
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -128,55 +173,25 @@ def main():
     queries = torch.randn((K + W, d), device=dev, dtype=torch.float32, generator=g)
     queries /= queries.norm(dim=1, keepdim=True)
 
-    # per-step output record: [k f32 scores | pad | k i64 rows] (svs_amd.sharded).
-    # N = 1: the final top-k kernel writes the record straight into pinned host
-    # memory (zero-copy, no D2H).  N > 1: records stay in HBM for the RCCL
-    # all-gather; rank 0 streams each gathered step back with an async copy.
-    # (A single bulk D2H after the loop cost 8-12 ms: the copy engine had idled.)
-    s_bytes, rec = record_layout(k)
-    G = max(1, args.gather_every) if world > 1 else 1           # steps per exchange
-    nchunks = (K + W + G - 1) // G
-    host_out = torch.zeros((nchunks, world, G * rec), dtype=torch.uint8, pin_memory=True)
-    local = None if world == 1 else torch.zeros((nchunks, G * rec), device=dev, dtype=torch.uint8)
-    gathered = torch.zeros((nchunks, world, G * rec), device=dev, dtype=torch.uint8) if world > 1 else None
-    streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.inflight if world == 1 else max(2, args.inflight)))]
+    # The exchange is the LIBRARY's (svs_amd.sharded.ShardedIndex, the same class the gloo tests
+    # drive): per step the search kernel writes the packed record [k f32 scores | pad | k i64 rows];
+    # N = 1: straight into pinned host memory (zero-copy, no D2H); N > 1: into HBM, one RCCL
+    # all-gather per `gather_every` steps on alternating HIP streams, rank 0 streams each gathered
+    # chunk home with an async copy and merges (host merge, H1).
+    sh = ShardedIndex(idx, n_total, device=dev, gather_every=args.gather_every,
+                      streams=(args.inflight if world == 1 else max(2, args.inflight)))
+    G = sh.gather_every
     count = min(k, n_local)
     torch.cuda.synchronize()
 
-    def step(i, last_of_run):
-        """One search; N > 1: after every G-th step (or the last of a run) one RCCL
-        all-gather moves the G local records of every rank, and rank 0 streams them home."""
-        c, j = divmod(i, G)
-        # consecutive searches alternate streams: the next query's score kernel fills the CUs
-        # that this query's small top-k kernels leave idle (125k-row shard: 0.117 vs 0.132 ms
-        # per step).  N = 1 keeps one stream unless --inflight says otherwise.
-        st = streams[i % len(streams)]
-        base = (host_out[c, 0] if world == 1 else local[c]).data_ptr() + j * rec
-        idx.search_device(queries[i].data_ptr(), 1, d, k, base, base + s_bytes, st.cuda_stream)
-        if world > 1 and (j == G - 1 or last_of_run):
-            for o in streams:          # the chunk's records were written on every stream
-                if o is not st:
-                    e = torch.cuda.Event()
-                    e.record(o)
-                    st.wait_event(e)
-            with torch.cuda.stream(st):
-                w = dist.all_gather_into_tensor(gathered[c].view(-1), local[c], async_op=True)
-                w.wait()   # orders this stream behind the collective; does not block the host
-                if rank == 0:
-                    host_out[c].copy_(gathered[c], non_blocking=True)
+    sh.open(K + W, k)          # buffers and streams: outside the timed region
+    torch.cuda.synchronize()
 
-    def finish(i0, i1):
-        """Drain the streams, then merge on rank 0 (host merge, H1)."""
-        torch.cuda.synchronize()
-        if rank != 0:
-            return None
-        res = []
+    def run_steps(i0, i1):
+        """Steps i0 .. i1-1 enqueued (searches + exchanges); collect() drains and merges."""
         for i in range(i0, i1):
-            c, j = divmod(i, G)
-            buf = host_out[c].numpy()[:, j * rec:(j + 1) * rec]
-            sc, rw = unpack_records(buf, world, k)
-            res.append(merge_topk(sc, rw, min(k, n_total)) if world > 1 else (sc[0, :count].copy(), rw[0, :count].copy()))
-        return res
+            sh.enqueue(queries[i].data_ptr(), d)
+        return sh
 
     def barrier():
         if world > 1:
@@ -187,19 +202,16 @@ def main():
     # stage events on every 4th step of the timed region: each timed step carries three event
     # records (~10 us of stream time); sampling keeps the probe from slowing what it measures
     idx.set_timing(0 if os.environ.get("SVS_BENCH_NOEVENTS") else args.time_every)
-    for i in range(W):
-        step(i, i == W - 1)
-    finish(0, W)
+    run_steps(0, W).collect()
     idx.get_timing()
     barrier()
     torch.cuda.synchronize()
 
     # ---- timed region: exactly K steps
     t0 = time.perf_counter()
-    for i in range(K):
-        step(W + i, i == K - 1)
+    run_steps(W, W + K)
     t_enq = time.perf_counter()
-    results = finish(W, W + K)
+    results = sh.collect(first=W)
     torch.cuda.synchronize()
     barrier()
     t1 = time.perf_counter()
@@ -287,6 +299,34 @@ def main():
                             "note": "host API (queries in, results out, synchronised)"})
     idx.set_timing(False)
 
+    # ---- secondary figures (N = 1 only; not `value`): BASELINE.json configs[2] and configs[4], the
+    # MFMA-bound batch configurations, each on its own index (synthetic, same recipe as the headline corpus)
+    configs = []
+    want = [c for c in str(args.configs).split(",") if c.strip()] if (world == 1 and args.dtype == "f32") else []
+    if "2" in want and n_total == 1_000_000 and d == 1536:
+        src = rows if keep_rows_for_cpu else gen_rows(torch, dev, args.seed, 0, n_total, d)
+        i2 = DeviceIndex.from_device_pointer(src.data_ptr(), n_total, d, device=dev_index, dtype="f16")
+        torch.cuda.synchronize()
+        if not keep_rows_for_cpu:
+            del src
+        configs.append(batched_config(torch, i2, "BASELINE.json configs[2]: 1M docs x dim 1536 fp16, top-100, batch 1024 queries, "
+                                      "MFMA GEMM + fused top-k", n_total, d, "f16", 1024, k, args.seed + 2, reps=10))
+        i2.release()
+        torch.cuda.empty_cache()
+    if "4" in want:
+        n4, d4, blk = 10_000_000, 3072, 500_000
+        i4 = DeviceIndex.empty(d4, device=dev_index, dtype="fp8", reserve=n4)
+        for b0 in range(0, n4, blk):           # the 123 GB f32 source never exists: one 6 GB block at a time
+            x = gen_rows(torch, dev, args.seed + 4, b0, b0 + blk, d4, block=blk)
+            torch.cuda.synchronize()
+            i4.append_device(x.data_ptr(), blk)
+            del x
+        torch.cuda.empty_cache()
+        configs.append(batched_config(torch, i4, "BASELINE.json configs[4]: 10M docs x dim 3072 fp8 (e4m3 + row scales), top-100, "
+                                      "batch 256 queries, fp8 MFMA GEMM + fused top-k", n4, d4, "fp8", 256, k, args.seed + 4, reps=5))
+        i4.release()
+        torch.cuda.empty_cache()
+
     out = None
     if rank == 0:
         kernel_ms = score_ms / max(launches, 1)
@@ -312,15 +352,16 @@ def main():
                             "HBM-resident GEMV + top-k" + ("" if world == 1 else ", row-sharded over %d GPUs + RCCL all-gather + host merge" % world),
                 "rows_per_gpu": n_local, "dim": d, "k": k, "queries_per_step": 1,
                 "corpus": "unit-norm gaussian, seed %d, generated on device" % args.seed,
-                "variant": args.variant, "searches_in_flight": len(streams),
+                "variant": args.variant, "searches_in_flight": sh.streams,
                 "steps_per_exchange": G if world > 1 else None,
             },
             "p50_latency_ms": lat_ms,
             "sharded_check": sharded_check,
             "batched": batched,
+            "configs": configs,
             "stage_ms": {"score": kernel_ms, "select": select_ms / max(launches, 1)},
             "roofline": {
-                "bound": "hbm", "kernel": "gemv_f32 score stage",
+                "bound": "hbm", "kernel": KERNEL_NAME[(args.dtype, 1)] if (n_local * d) else "-",
                 "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": launches,
@@ -335,7 +376,11 @@ def main():
         m_host = rows.cpu().numpy()
         del rows
         torch.cuda.empty_cache()
-        qh = queries[W:W + 3 + args.cpu_iters].cpu().numpy()
+        # its own 3 + cpu_iters queries (the driver's --steps 20 --warmup 5 leaves only 25 in `queries`)
+        gc = torch.Generator(device=dev)
+        gc.manual_seed(args.seed + 4242)
+        qh = torch.randn((3 + args.cpu_iters, d), device=dev, dtype=torch.float32, generator=gc)
+        qh = (qh / qh.norm(dim=1, keepdim=True)).cpu().numpy()
         for q in qh[:3]:
             oracle.cpu_search(m_host, q, k)
         ts = []

@@ -69,6 +69,9 @@ typedef struct svs_timing_t {
   double score_ms_sum;  /* dominant kernel: query x corpus GEMV/GEMM            */
   double select_ms_sum; /* top-k select + order kernels                          */
   int64_t launches;     /* number of searches accumulated                        */
+  double dominant_ms_sum; /* the ONE dominant kernel launch inside the score stage: for a fused batched
+                             search the whole-corpus GEMM (without query staging and the prefix pass that
+                             seeds its thresholds); otherwise equal to score_ms_sum              */
 } svs_timing_t;
 
 /* ---- library ------------------------------------------------------------- */

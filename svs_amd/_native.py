@@ -43,6 +43,7 @@ class Timing(C.Structure):
         ("score_ms_sum", C.c_double),
         ("select_ms_sum", C.c_double),
         ("launches", C.c_int64),
+        ("dominant_ms_sum", C.c_double),
     ]
 
 

@@ -52,6 +52,7 @@ int fail(int code, const char* fmt, ...) {
 
 struct EvTriple {
   hipEvent_t e0, e1, e2;
+  hipEvent_t d0 = nullptr, d1 = nullptr;   // around the dominant kernel of a fused search (else unset)
 };
 
 // One in-flight search: stream, device scratch, pinned staging.
@@ -146,6 +147,8 @@ void index_destroy(svs_index* idx) {
     (void)hipEventDestroy(t.e0);
     (void)hipEventDestroy(t.e1);
     (void)hipEventDestroy(t.e2);
+    if (t.d0) (void)hipEventDestroy(t.d0);
+    if (t.d1) (void)hipEventDestroy(t.d1);
   }
   (void)hipFree(idx->rows);
   (void)hipFree(idx->row_scales);
@@ -800,7 +803,13 @@ int enqueue_search(svs_index* idx, Ctx* c, const float* q_dev, int nq, int k, in
       return rc;
     // 2. the whole corpus, keeping only scores >= threshold
     FuseLaunch fl{c->hist, c->cand, kth ? c->pref_s : c->pref_s + (count - 1), kth ? 1 : count};
+    if (timed) {
+      HIP_TRY(hipEventCreate(&ev.d0));
+      HIP_TRY(hipEventCreate(&ev.d1));
+      HIP_TRY(hipEventRecord(ev.d0, st));
+    }
     if ((rc = launch_scores_any(idx, c, q_dev, n, nq, nullptr, 0, fl, st, false)) != SVS_OK) return rc;
+    if (timed) HIP_TRY(hipEventRecord(ev.d1, st));
     if (timed) HIP_TRY(hipEventRecord(ev.e1, st));
     hipLaunchKernelGGL(select_final_kernel, dim3(nq), dim3(FINAL_THREADS), 0, st, (const float*)nullptr, n, (int64_t)0, k, count, 3,
                        c->hist, c->cand, idx->row_offset, out_s, out_r,
@@ -1446,15 +1455,19 @@ int32_t svs_index_get_timing(svs_index* idx, svs_timing_t* out) {
   out->score_ms_sum = 0;
   out->select_ms_sum = 0;
   out->launches = 0;
+  out->dominant_ms_sum = 0;
   int rc = SVS_OK;
   for (auto& t : evs) {
     float a = 0, b = 0;
     hipError_t e = hipEventSynchronize(t.e2);
     if (e == hipSuccess) e = hipEventElapsedTime(&a, t.e0, t.e1);
     if (e == hipSuccess) e = hipEventElapsedTime(&b, t.e1, t.e2);
+    float dm = a;
+    if (e == hipSuccess && t.d0 && t.d1) e = hipEventElapsedTime(&dm, t.d0, t.d1);
     if (e == hipSuccess) {
       out->score_ms_sum += a;
       out->select_ms_sum += b;
+      out->dominant_ms_sum += dm;
       out->launches++;
     } else {
       rc = fail(SVS_ERR_DEVICE, "timing events: %s", hipGetErrorString(e));
@@ -1462,6 +1475,8 @@ int32_t svs_index_get_timing(svs_index* idx, svs_timing_t* out) {
     (void)hipEventDestroy(t.e0);
     (void)hipEventDestroy(t.e1);
     (void)hipEventDestroy(t.e2);
+    if (t.d0) (void)hipEventDestroy(t.d0);
+    if (t.d1) (void)hipEventDestroy(t.d1);
   }
   return rc;
 }

@@ -276,6 +276,7 @@ class DeviceIndex:
     def get_timing(self) -> Tuple[float, float, int]:
         t = _native.Timing()
         _native.check(self._lib.svs_index_get_timing(self._handle(), C.byref(t)))
+        self.last_dominant_ms_sum = float(t.dominant_ms_sum)   # the dominant kernel alone (bench.py's roofline)
         return float(t.score_ms_sum), float(t.select_ms_sum), int(t.launches)
 
     def set_variant(self, variant: int) -> None:

@@ -23,7 +23,29 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 from .index import DeviceIndex
-from .sharded import merge_topk, shard_bounds
+from .sharded import merge_topk_batch, shard_bounds
+
+
+class _SharedPool:
+    """One worker per shard, shared by an index and its share()d copies (share() runs on every
+    AsyncKB search: it must not spawn threads); shut down when the last holder lets go."""
+
+    def __init__(self, workers: int):
+        self.ex = ThreadPoolExecutor(max_workers=max(1, workers))
+        self._refs = 1
+        self._mu = threading.Lock()
+
+    def retain(self) -> "_SharedPool":
+        with self._mu:
+            self._refs += 1
+        return self
+
+    def release(self) -> None:
+        with self._mu:
+            self._refs -= 1
+            last = self._refs == 0
+        if last:
+            self.ex.shutdown(wait=False)
 
 
 class MultiDeviceIndex:
@@ -31,7 +53,7 @@ class MultiDeviceIndex:
     search_batch, scores, append, mask_rows, share, release, shape)."""
 
     def __init__(self, matrix: Optional[np.ndarray], devices: Sequence[int] = (0,), device: Optional[int] = None,
-                 dtype: str = "f32", *, _shards: Optional[List[DeviceIndex]] = None, _bounds=None):
+                 dtype: str = "f32", *, _shards: Optional[List[DeviceIndex]] = None, _bounds=None, _pool=None):
         if _shards is not None:
             self._shards, self._bounds = _shards, list(_bounds)
         else:
@@ -52,7 +74,8 @@ class MultiDeviceIndex:
                 for s in self._shards:
                     s.release()
                 raise
-        self._pool = ThreadPoolExecutor(max_workers=max(1, len(self._shards)))
+        self._pool_ref = _pool if _pool is not None else _SharedPool(len(self._shards))
+        self._pool = self._pool_ref.ex
         self._mu = threading.Lock()
         self.d = self._shards[0].d
         self.dtype = self._shards[0].dtype
@@ -80,12 +103,12 @@ class MultiDeviceIndex:
 
     # -- lifetime -------------------------------------------------------------
     def share(self) -> "MultiDeviceIndex":
-        return MultiDeviceIndex(None, _shards=[s.share() for s in self._shards], _bounds=self._bounds)
+        return MultiDeviceIndex(None, _shards=[s.share() for s in self._shards], _bounds=self._bounds, _pool=self._pool_ref.retain())
 
     def release(self) -> None:
         for s in self._shards:
             s.release()
-        self._pool.shutdown(wait=False)
+        self._pool_ref.release()
 
     close = release
 
@@ -102,13 +125,15 @@ class MultiDeviceIndex:
         parts = list(self._pool.map(lambda s: s.search_batch(q, n), live))
         k = max(n, 0)
         count = min(k, self.n - self.n_masked)
-        out_s = np.empty((q.shape[0], count), dtype=np.float32)
-        out_r = np.empty((q.shape[0], count), dtype=np.int64)
-        for i in range(q.shape[0]):
-            s = np.concatenate([p[0][i] for p in parts])
-            r = np.concatenate([p[1][i] for p in parts])
-            out_s[i], out_r[i] = merge_topk(s, r, count)
-        return out_s, out_r
+        # shards return min(k, their live rows) each: pad to a common width, then ONE lexsort over
+        # the (nq, G * width) table (was: a Python loop of nq sorts)
+        width = max(p[0].shape[1] for p in parts)
+        sc = np.full((len(parts), q.shape[0], width), -np.inf, dtype=np.float32)
+        rw = np.full((len(parts), q.shape[0], width), -1, dtype=np.int64)
+        for g, (ps, pr) in enumerate(parts):
+            sc[g, :, : ps.shape[1]] = ps
+            rw[g, :, : pr.shape[1]] = pr
+        return merge_topk_batch(sc, rw, count)
 
     def search(self, query_vec: np.ndarray, n: int) -> List[Tuple[float, int]]:
         assert isinstance(n, int)

@@ -44,56 +44,100 @@ def merge_topk(scores: np.ndarray, rows: np.ndarray, k: int) -> Tuple[np.ndarray
     return scores[order], rows[order]
 
 
-# ---- wire format of one rank's local top-k (one query) -----------------------
-# [k f32 scores | pad to 8 B | k i64 global rows]; entries past the shard's count
-# carry row = -1.  Exchanged as raw bytes so ONE collective moves both arrays.
-def record_layout(k: int) -> Tuple[int, int]:
+def merge_topk_batch(scores: np.ndarray, rows: np.ndarray, k: int) -> Tuple[np.ndarray, np.ndarray]:
+    """``merge_topk`` for nq queries at once: ``scores``/``rows`` are (G, nq, k') candidate lists
+    (padding entries: score -inf, row -1).  ONE lexsort over the (nq, G*k') table instead of nq
+    Python-level sorts.  Returns (nq, k) arrays; requires every query to have >= k live candidates
+    (true whenever k <= rows in the corpus: each shard returns min(k', its rows))."""
+    g, nq, kk = scores.shape
+    sc = np.ascontiguousarray(np.transpose(scores, (1, 0, 2))).reshape(nq, g * kk).astype(np.float32, copy=False)
+    rw = np.ascontiguousarray(np.transpose(rows, (1, 0, 2))).reshape(nq, g * kk).astype(np.int64, copy=False)
+    key = sc + np.float32(0.0)                      # -0.0 == +0.0 (python compares them equal)
+    # padding (row -1) must lose against a real row with the same score (-inf): row is the tie-break anyway
+    order = np.lexsort((rw, key), axis=-1)[:, ::-1][:, : max(k, 0)]
+    return np.take_along_axis(sc, order, axis=1), np.take_along_axis(rw, order, axis=1)
+
+
+# ---- wire format of one rank's local top-k ---------------------------------------
+# One record = the result of ONE search call of nq queries:
+#   [nq*k f32 scores | pad to 8 B | nq*k i64 global rows];  entries past a shard's count carry
+# score -inf, row -1.  It is exactly what svs_index_search_device writes (scores at the record's
+# start, rows at `record_layout()[0]`), so the GPU path never touches the result on the host
+# before the exchange, and ONE collective moves both arrays.
+def record_layout(k: int, nq: int = 1) -> Tuple[int, int]:
     """(offset of the row array, record bytes)."""
-    s_bytes = (k * 4 + 7) // 8 * 8
-    return s_bytes, s_bytes + k * 8
+    s_bytes = (nq * k * 4 + 7) // 8 * 8
+    return s_bytes, s_bytes + nq * k * 8
 
 
-def unpack_records(buf: np.ndarray, world: int, k: int) -> Tuple[np.ndarray, np.ndarray]:
-    """``buf``: uint8 (world, record_bytes) -> (scores f32 (world,k), rows i64 (world,k))."""
-    s_bytes, rec = record_layout(k)
+def unpack_records(buf: np.ndarray, world: int, k: int, nq: int = 1) -> Tuple[np.ndarray, np.ndarray]:
+    """``buf``: uint8 (world, record_bytes) -> (scores f32 (world, nq*k), rows i64 (world, nq*k))."""
+    s_bytes, rec = record_layout(k, nq)
     buf = np.ascontiguousarray(buf, dtype=np.uint8).reshape(world, rec)
-    sc = np.ascontiguousarray(buf[:, : k * 4]).view(np.float32).reshape(world, k)
-    rw = np.ascontiguousarray(buf[:, s_bytes:]).view(np.int64).reshape(world, k)
+    sc = np.ascontiguousarray(buf[:, : nq * k * 4]).view(np.float32).reshape(world, nq * k)
+    rw = np.ascontiguousarray(buf[:, s_bytes:]).view(np.int64).reshape(world, nq * k)
     return sc, rw
 
 
-def pack_record(scores: np.ndarray, rows: np.ndarray, k: int) -> np.ndarray:
-    """Host-side packer (tests / CPU paths); the GPU path has the search kernel
-    write both arrays straight into the record."""
-    s_bytes, rec = record_layout(k)
+def pack_record(scores: np.ndarray, rows: np.ndarray, k: int, nq: int = 1) -> np.ndarray:
+    """Host-side packer (host/CPU path and tests): ``scores``/``rows`` (nq, c) with c <= k, or 1-D
+    for one query.  The GPU path has the search kernel write both arrays straight into the record."""
+    s_bytes, rec = record_layout(k, nq)
     out = np.zeros(rec, dtype=np.uint8)
-    sc = np.full(k, -np.inf, dtype=np.float32)
-    rw = np.full(k, -1, dtype=np.int64)
-    sc[: len(scores)] = scores
-    rw[: len(rows)] = rows
-    out[: k * 4] = sc.view(np.uint8)
-    out[s_bytes:] = rw.view(np.uint8)
+    sc = np.full((nq, k), -np.inf, dtype=np.float32)
+    rw = np.full((nq, k), -1, dtype=np.int64)
+    scores = np.asarray(scores, dtype=np.float32).reshape(nq, -1)
+    rows = np.asarray(rows, dtype=np.int64).reshape(nq, -1)
+    sc[:, : scores.shape[1]] = scores
+    rw[:, : rows.shape[1]] = rows
+    out[: nq * k * 4] = sc.reshape(-1).view(np.uint8)
+    out[s_bytes:] = rw.reshape(-1).view(np.uint8)
     return out
 
 
 class ShardedIndex:
-    """Distributed wrapper: ``local_search(queries (nq,d) f32, k) ->
-    (scores (nq,c) f32, rows (nq,c) i64 GLOBAL)`` is the per-rank search (a
-    ``DeviceIndex.search_batch`` built with ``row_offset = shard_bounds()[0]``);
-    this class adds the gather + merge.  Results are returned on ``dst`` (None
-    elsewhere)."""
+    """One process per GPU: rank r holds rows ``shard_bounds(N, G, r)``; this class owns the
+    exchange + merge.  ``local`` is either
 
-    def __init__(self, local_search: Callable[[np.ndarray, int], Tuple[np.ndarray, np.ndarray]],
-                 n_total: int, group=None, dst: int = 0, device=None):
+    * a ``DeviceIndex`` built with ``row_offset = shard_bounds()[0]`` plus a torch ``device``:
+      the search kernel writes the packed record into HBM, ONE ``all_gather_into_tensor`` (RCCL)
+      moves the records of every rank, ``dst`` copies them home and merges; or
+    * a callable ``local_search(queries (nq,d) f32, k) -> (scores (nq,c), rows (nq,c) GLOBAL)``:
+      the host path (CPU tests over gloo; any backend whose results are numpy arrays).
+
+    Two ways to drive it: ``search`` / ``search_batch`` (blocking, one record, one collective per
+    call) and the pipelined pair ``open`` + ``enqueue`` / ``collect`` that ``bench.py`` measures
+    (single-query searches alternate between HIP streams, ``gather_every`` records share one
+    collective, ``dst`` streams them back with an async copy).  Results arrive on ``dst`` (None
+    elsewhere) and are identical for every G: a row's score does not depend on where it lives."""
+
+    def __init__(self, local, n_total: int, group=None, dst: int = 0, device=None, *,
+                 gather_every: int = 8, streams: int = 2):
         import torch.distributed as dist
         self._dist = dist
-        self.local_search = local_search
+        self.local = local
+        self._on_device = device is not None and hasattr(local, "search_device")
+        self.local_search = None if self._on_device else (local.search_batch if hasattr(local, "search_batch") else local)
         self.n_total = int(n_total)
         self.group = group
         self.dst = dst
         self.device = device
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.gather_every = max(1, int(gather_every)) if self.world > 1 else 1
+        self._n_streams = max(1, int(streams)) if self.world == 1 else max(2, int(streams))
+        self._pipe = None
+        self._rec_cache = {}
+
+    # ---- one record, one collective -------------------------------------------------
+    def _exchange(self, rec):
+        """rec: uint8 tensor (record bytes) of this rank -> uint8 (world, record bytes) on dst, else None."""
+        import torch
+        if self.world == 1:
+            return rec[None]
+        out = torch.empty((self.world, rec.numel()), dtype=torch.uint8, device=rec.device)
+        self._dist.all_gather_into_tensor(out.view(-1), rec, group=self.group)
+        return out if self.rank == self.dst else None
 
     def search_batch(self, queries: np.ndarray, n: int) -> Optional[Tuple[np.ndarray, np.ndarray]]:
         import torch
@@ -101,37 +145,114 @@ class ShardedIndex:
         q = np.ascontiguousarray(queries, dtype=np.float32)
         nq = q.shape[0]
         k = max(n, 0)
-        ls, lr = self.local_search(q, k)
-        # fixed-size message: pad every shard's list to k (a shard may hold < k rows)
-        ps = np.full((nq, k), -np.inf, dtype=np.float32)
-        pr = np.full((nq, k), -1, dtype=np.int64)
-        ps[:, : ls.shape[1]] = ls
-        pr[:, : lr.shape[1]] = lr
-        if self.world == 1:
-            gs, gr = ps[None], pr[None]
-        else:
-            ts = torch.from_numpy(ps)
-            tr = torch.from_numpy(pr)
-            if self.device is not None:
-                ts, tr = ts.to(self.device), tr.to(self.device)
-            outs = [torch.empty_like(ts) for _ in range(self.world)] if self.rank == self.dst else None
-            outr = [torch.empty_like(tr) for _ in range(self.world)] if self.rank == self.dst else None
-            self._dist.gather(ts, outs, dst=self.dst, group=self.group)
-            self._dist.gather(tr, outr, dst=self.dst, group=self.group)
-            if self.rank != self.dst:
-                return None
-            gs = torch.stack(outs).cpu().numpy()
-            gr = torch.stack(outr).cpu().numpy()
         count = min(k, self.n_total)
-        out_s = np.empty((nq, count), dtype=np.float32)
-        out_r = np.empty((nq, count), dtype=np.int64)
-        for i in range(nq):
-            s, r = merge_topk(gs[:, i, :], gr[:, i, :], count)
-            out_s[i], out_r[i] = s, r
-        return out_s, out_r
+        if k == 0 or nq == 0:
+            return (np.empty((nq, 0), np.float32), np.empty((nq, 0), np.int64)) if self.rank == self.dst else None
+        s_bytes, rec_bytes = record_layout(k, nq)
+        if self._on_device:
+            qt = torch.from_numpy(q).to(self.device)
+            rec = torch.empty(rec_bytes, dtype=torch.uint8, device=self.device)
+            st = torch.cuda.current_stream(self.device)
+            self.local.search_device(qt.data_ptr(), nq, q.shape[1], k, rec.data_ptr(), rec.data_ptr() + s_bytes, st.cuda_stream)
+            got = self._exchange(rec)
+            if got is None:
+                return None
+            buf = got.cpu().numpy()                     # (synchronises this stream)
+        else:
+            ls, lr = self.local_search(q, k)
+            rec = torch.from_numpy(pack_record(ls, lr, k, nq))
+            if self.device is not None:
+                rec = rec.to(self.device)
+            got = self._exchange(rec)
+            if got is None:
+                return None
+            buf = got.cpu().numpy()
+        sc, rw = unpack_records(buf, self.world, k, nq)
+        return merge_topk_batch(sc.reshape(self.world, nq, k), rw.reshape(self.world, nq, k), count)
 
     def search(self, query_vec: np.ndarray, n: int) -> Optional[List[Tuple[float, int]]]:
         res = self.search_batch(np.asarray(query_vec, dtype=np.float32)[None, :], n)
         if res is None:
             return None
         return [(float(a), int(b)) for a, b in zip(res[0][0], res[1][0])]
+
+    # ---- pipelined single-query searches (device path; what bench.py times) ----------------
+    def open(self, capacity: int, k: int) -> None:
+        """Buffers for up to ``capacity`` enqueued single-query searches of top-``k``."""
+        import torch
+        assert self._on_device, "the pipelined path needs a DeviceIndex and a torch device"
+        s_bytes, rec = record_layout(k)
+        g = self.gather_every
+        nchunks = (capacity + g - 1) // g
+        dev = self.device
+        p = {"k": k, "rec": rec, "s_bytes": s_bytes, "n": 0, "sent": 0, "nchunks": nchunks,
+             # N = 1: the final top-k kernel writes the record straight into pinned host memory
+             # (zero-copy, no D2H).  N > 1: records stay in HBM for the RCCL all-gather; dst streams
+             # each gathered chunk home with an async copy.
+             "host": torch.zeros((nchunks, self.world, g * rec), dtype=torch.uint8, pin_memory=True),
+             "local": None if self.world == 1 else torch.zeros((nchunks, g * rec), device=dev, dtype=torch.uint8),
+             "gathered": None if self.world == 1 else torch.zeros((nchunks, self.world, g * rec), device=dev, dtype=torch.uint8),
+             "streams": [torch.cuda.Stream(device=dev) for _ in range(self._n_streams)]}
+        self._pipe = p
+
+    def _send_chunk(self, c: int, st) -> None:
+        """One all-gather for chunk c (its records were written on every stream), issued on `st`."""
+        import torch
+        p = self._pipe
+        for o in p["streams"]:
+            if o is not st:
+                e = torch.cuda.Event()
+                e.record(o)
+                st.wait_event(e)
+        with torch.cuda.stream(st):
+            w = self._dist.all_gather_into_tensor(p["gathered"][c].view(-1), p["local"][c], group=self.group, async_op=True)
+            w.wait()    # orders this stream behind the collective; does not block the host
+            if self.rank == self.dst:
+                p["host"][c].copy_(p["gathered"][c], non_blocking=True)
+        p["sent"] = c + 1
+
+    def enqueue(self, query_ptr: int, d: int) -> int:
+        """Enqueue one search (device pointer to d f32) without synchronising; returns its ticket.
+        Consecutive searches alternate streams: the next query's score kernel fills the CUs this
+        query's small top-k kernels leave idle.  Every ``gather_every``-th one issues the exchange."""
+        p = self._pipe
+        i = p["n"]
+        g = self.gather_every
+        c, j = divmod(i, g)
+        assert c < p["nchunks"], "ShardedIndex.open(capacity) exceeded"
+        st = p["streams"][i % len(p["streams"])]
+        base = (p["host"][c, 0] if self.world == 1 else p["local"][c]).data_ptr() + j * p["rec"]
+        self.local.search_device(query_ptr, 1, d, p["k"], base, base + p["s_bytes"], st.cuda_stream)
+        p["n"] = i + 1
+        if self.world > 1 and j == g - 1:
+            self._send_chunk(c, st)
+        return i
+
+    def collect(self, first: int = 0) -> Optional[List[Tuple[np.ndarray, np.ndarray]]]:
+        """Exchanges a partly filled last chunk, drains the streams, and merges tickets
+        ``first`` .. on ``dst`` (host merge under the single-index total order).  Collective:
+        every rank calls it at the same point."""
+        import torch
+        p = self._pipe
+        g = self.gather_every
+        if self.world > 1 and p["n"] > p["sent"] * g:
+            last = p["n"] - 1
+            self._send_chunk(last // g, p["streams"][last % len(p["streams"])])
+        torch.cuda.synchronize(self.device)
+        if self.rank != self.dst:
+            return None
+        k, rec = p["k"], p["rec"]
+        count = min(k, self.n_total)
+        out = []
+        for i in range(first, p["n"]):
+            c, j = divmod(i, g)
+            sc, rw = unpack_records(p["host"][c].numpy()[:, j * rec:(j + 1) * rec], self.world, k)
+            if self.world == 1:
+                out.append((sc[0, :count].copy(), rw[0, :count].copy()))
+            else:
+                out.append(merge_topk(sc, rw, count))
+        return out
+
+    @property
+    def streams(self) -> int:
+        return self._n_streams

@@ -11,7 +11,7 @@ import pytest
 from oracle import svs_oracle as oracle
 from synth import corpus_and_query
 
-from svs_amd.sharded import (ShardedIndex, merge_topk, pack_record, record_layout, shard_bounds,
+from svs_amd.sharded import (ShardedIndex, merge_topk, merge_topk_batch, pack_record, record_layout, shard_bounds,
                              unpack_records)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -66,6 +66,40 @@ def test_record_wire_format_roundtrip():
             assert np.all(rw[r, c:] == -1) and np.all(np.isneginf(sc[r, c:]))
         ms, mr = merge_topk(sc, rw, k)
         assert len(ms) == k and np.all(np.diff(ms) <= 0) and np.all(mr >= 0)
+
+
+def test_batched_merge_equals_per_query_merge():
+    """merge_topk_batch (one lexsort over (nq, G*k)) == merge_topk query by query, with ties,
+    signed zeros, padding and a NaN (MultiDeviceIndex / ShardedIndex use the batched form)."""
+    rng = np.random.default_rng(1)
+    g, nq, k = 4, 9, 20
+    sc = rng.standard_normal((g, nq, k)).astype(np.float32)
+    rw = rng.integers(0, 10 ** 6, (g, nq, k))
+    sc[0, :, 5] = 0.0; sc[1, :, 3] = -0.0; sc[2, :, 7:] = -np.inf; rw[2, :, 7:] = -1
+    sc[:, :, 11] = 0.25                       # a tie across every shard
+    sc[3, 2, 1] = np.nan
+    bs, br = merge_topk_batch(sc, rw, 15)
+    for i in range(nq):
+        ms, mr = merge_topk(sc[:, i, :], rw[:, i, :], 15)
+        assert np.array_equal(mr, br[i]) and np.array_equal(ms, bs[i], equal_nan=True)
+
+
+def test_record_of_a_query_batch():
+    """A record holds the result of ONE call of nq queries: [nq*k scores | pad | nq*k rows]."""
+    k, nq, world = 7, 5, 3
+    s_off, rec = record_layout(k, nq)
+    assert s_off % 8 == 0 and s_off >= nq * k * 4 and rec == s_off + nq * k * 8
+    rng = np.random.default_rng(3)
+    recs, ss, rr = [], [], []
+    for r in range(world):
+        sc = -np.sort(-rng.standard_normal((nq, k - r)).astype(np.float32), axis=1)
+        rw = rng.integers(0, 1 << 40, (nq, k - r))
+        recs.append(pack_record(sc, rw, k, nq)); ss.append(sc); rr.append(rw)
+    sc, rw = unpack_records(np.stack(recs), world, k, nq)
+    sc, rw = sc.reshape(world, nq, k), rw.reshape(world, nq, k)
+    for r in range(world):
+        assert np.array_equal(sc[r, :, : k - r], ss[r]) and np.array_equal(rw[r, :, : k - r], rr[r])
+        assert np.all(rw[r, :, k - r:] == -1)
 
 
 def _bench_like_worker(rank, world, port, out_q):
@@ -223,3 +257,30 @@ def test_multi_device_index_in_one_process(gpu):
     tiny = MultiDeviceIndex(m[:2], devices=[0, 0, 0, 0])          # fewer rows than shards
     assert [r for _, r in tiny.search(qs[0], 5)] == [r for _, r in oracle.total_order_top_k(oracle.cpu_scores(m[:2], qs[0]), 5)]
     tiny.release()
+
+
+@pytest.mark.gpu
+def test_pipelined_exchange_world1_equals_search(gpu):
+    """ShardedIndex's pipelined path (what bench.py times) at one rank: records written by the
+    search kernel straight into pinned host memory, alternating streams -- identical to the blocking
+    search, query by query; and the blocking record path (search_batch) likewise."""
+    import torch
+    from svs_amd import DeviceIndex
+    n, d, k = 60000, 1536, 100
+    m, qs = corpus_and_query("gaussian", 47, n, d, 21)
+    idx = DeviceIndex(m, row_offset=5_000_000)
+    dev = torch.device("cuda:0")
+    sh = ShardedIndex(idx, n_total=n, device=dev, gather_every=8, streams=2)
+    qt = torch.from_numpy(qs).to(dev)
+    sh.open(len(qs), k)
+    for i in range(len(qs)):
+        assert sh.enqueue(qt[i].data_ptr(), d) == i
+    res = sh.collect()
+    for i, (s, r) in enumerate(res):
+        one = idx.search(qs[i], k)
+        assert [int(x) for x in r] == [x for _, x in one] and [float(x) for x in s] == [x for x, _ in one]
+    bs, br = sh.search_batch(qs, k)
+    ws, wr = idx.search_batch(qs, k)
+    assert np.array_equal(bs, ws) and np.array_equal(br, wr)
+    assert sh.search(qs[3], 7) == idx.search(qs[3], 7)
+    idx.release()
