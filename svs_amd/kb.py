@@ -518,3 +518,81 @@ class AsyncKB:
             res = await loop.run_in_executor(None, heavy)
         _LOG.info(f"retrieved top {n} documents")
         return res
+
+    async def retrieve_many(self, queries: List[str], n: int) -> List[List[Dict[str, Any]]]:
+        """Async twin of ``KB.retrieve_many``.  Same structure as
+        ``retrieve`` (reference src/svs/kb.py:1171-1206): the matrix is fetched under the lock, the
+        batched search runs on an executor thread OUTSIDE it on a held reference, and every result
+        list is fetched with one ``IN (...)`` statement.  Element i equals ``retrieve(queries[i], n)``."""
+        _LOG.info(f"retrieving {n} documents for each of {len(queries)} query strings")
+        loop = asyncio.get_running_loop()
+        async with self._get_lock():
+            db = await self._ensure_db()
+            await self.embeddings_matrix.get(db)
+            idx, lookup = self.embeddings_matrix.hold()
+        try:
+            vecs: List[List[float]] = []
+            for c0 in range(0, len(queries), BULK_EMBEDDING_CHUNK_SIZE):
+                vecs.extend(await self._embed(queries[c0:c0 + BULK_EMBEDDING_CHUNK_SIZE]))
+            if not vecs:
+                return []
+            _LOG.info("got embeddings for the queries!")
+            qmat = np.array(vecs, dtype=np.float32)
+
+            def superheavy() -> List[List[Tuple[float, int]]]:
+                scores, rows = idx.search_batch(qmat, n)
+                arr = lookup.arr
+                return [[(float(s), int(arr[r])) for s, r in zip(scores[i], rows[i])] for i in range(len(scores))]
+
+            per_query = await loop.run_in_executor(None, superheavy)
+            _LOG.info(f"computed {idx.shape[0]} x {len(vecs)} cosine similarities")
+        finally:
+            idx.release()
+        async with self._get_lock():
+            db = await self._ensure_db()
+
+            def heavy() -> List[List[Dict[str, Any]]]:
+                out: List[List[Dict[str, Any]]] = []
+                with db.transaction():
+                    for emb_ids in per_query:
+                        docs = db.fetch_docs_for_embeddings([e for _, e in emb_ids])
+                        out.append([{"score": s, "doc": docs[e]} for s, e in emb_ids])
+                return out
+
+            res = await loop.run_in_executor(None, heavy)
+        _LOG.info(f"retrieved top {n} documents for {len(queries)} queries")
+        return res
+
+    async def document_top_pairwise_scores(self, n: int) -> List[Tuple[float, Dict[str, Any], Dict[str, Any]]]:
+        """Reference src/svs/kb.py:1208-1243 (async twin of :1642-1671): the n most similar document
+        pairs, [(score, doc_1, doc_2)].  ``superheavy`` -- there ``np.dot(M, M.T)`` + ``get_top_pairs``
+        (src/svs/kb.py:1219, src/svs/util.py:206-233) -- is svs_index_top_pairs on an executor
+        thread, outside the lock, on a held reference."""
+        loop = asyncio.get_running_loop()
+        async with self._get_lock():
+            db = await self._ensure_db()
+            await self.embeddings_matrix.get(db)
+            idx, lookup = self.embeddings_matrix.hold()
+        try:
+            n_docs = idx.shape[0]
+            _LOG.info(f"computing pairwise similarity over {n_docs} documents")
+
+            def superheavy() -> List[Tuple[float, int, int]]:
+                res = idx.top_pairs(n)
+                arr = lookup.arr
+                return [(score, int(arr[i]), int(arr[j])) for score, i, j in res]
+
+            pairs = await loop.run_in_executor(None, superheavy)
+            _LOG.info(f"computed {n_docs * n_docs} pairwise cosine similarities")
+        finally:
+            idx.release()
+        async with self._get_lock():
+            db = await self._ensure_db()
+
+            def heavy() -> Dict[int, Dict[str, Any]]:
+                with db.transaction():
+                    return db.fetch_docs_for_embeddings(sorted({e for _, a, b in pairs for e in (a, b)}))
+
+            docs = await loop.run_in_executor(None, heavy)
+        _LOG.info(f"retrieved top {n} document pairs")
+        return [(score, docs[a], docs[b]) for score, a, b in pairs]

@@ -91,3 +91,38 @@ def test_kb_with_a_reduced_precision_corpus(gpu, tmp_path, dtype):
     many = kb.retrieve_many([f"doc {i}" for i in range(40)], 3)
     assert [r[0]["doc"]["text"] for r in many] == [f"doc {i}" for i in range(40)]
     kb.close()
+
+
+def test_async_kb_retrieve_many_and_pairs_on_hip(gpu, tmp_path):
+    """AsyncKB.retrieve_many / document_top_pairwise_scores (reference src/svs/kb.py:1208-1243) on the
+    HIP path: equal to the sync KB over the same file; element i of retrieve_many equals retrieve(i)."""
+    import asyncio
+    import svs_amd
+    rng = np.random.default_rng(11)
+    vecs = rng.standard_normal((600, 256))
+    vecs /= np.linalg.norm(vecs, axis=1, keepdims=True)
+    table = {f"doc {i}": [float(x) for x in vecs[i]] for i in range(600)}
+
+    async def ef(texts):
+        return [table[t] for t in texts]
+
+    path = str(tmp_path / "async_many.sqlite")
+    kb = svs_amd.KB(path, ef)
+    with kb.bulk_add_docs() as add_doc:
+        for i in range(500):
+            add_doc(f"doc {i}")
+    qs = [f"doc {i}" for i in list(range(0, 500, 13)) + [550, 599]]
+    want_many = kb.retrieve_many(qs, 9)
+    want_pairs = kb.document_top_pairwise_scores(50)
+    kb.close()
+
+    async def run():
+        akb = svs_amd.AsyncKB(path, ef)
+        got_many, got_pairs = await asyncio.gather(akb.retrieve_many(qs, 9), akb.document_top_pairwise_scores(50))
+        assert got_many == want_many
+        assert [(s, a["id"], b["id"]) for s, a, b in got_pairs] == [(s, a["id"], b["id"]) for s, a, b in want_pairs]
+        for i in (0, 5, len(qs) - 1):
+            assert await akb.retrieve(qs[i], 9) == got_many[i]
+        await akb.close()
+
+    asyncio.run(run())

@@ -71,6 +71,46 @@ def test_document_top_pairwise_scores(tmp_path):
     kb.close()
 
 
+def test_async_retrieve_many_and_top_pairs(tmp_path):
+    """AsyncKB twins (reference src/svs/kb.py:1208-1243 for the pairs; retrieve_many is SURVEY 8(f)
+    rank 3): equal to the sync KB on the same file, element by element, and safe to run concurrently
+    with each other and with an add (the searches hold their own reference to the matrix)."""
+    rng = np.random.default_rng(7)
+    vecs = rng.standard_normal((150, 16)); vecs /= np.linalg.norm(vecs, axis=1, keepdims=True)
+    table = {f"doc {i}": [float(x) for x in vecs[i]] for i in range(150)}
+
+    async def ef(texts):
+        return [table[t] for t in texts]
+
+    path = str(tmp_path / "amany.sqlite")
+    kb = svs_amd.KB(path, ef, index_factory=OracleIndex)
+    with kb.bulk_add_docs() as add_doc:
+        for i in range(100):
+            add_doc(f"doc {i}", meta={"i": i})
+    qs = [f"doc {i}" for i in (5, 17, 99, 101, 149)]
+    want_many = kb.retrieve_many(qs, 7)
+    want_pairs = kb.document_top_pairwise_scores(12)
+    kb.close()
+
+    async def run():
+        akb = svs_amd.AsyncKB(path, ef, index_factory=OracleIndex)
+        got_many, got_pairs, one = await asyncio.gather(akb.retrieve_many(qs, 7), akb.document_top_pairwise_scores(12),
+                                                        akb.retrieve(qs[0], 7))
+        assert got_many == want_many and one == want_many[0]
+        assert [(s, a["id"], b["id"]) for s, a, b in got_pairs] == [(s, a["id"], b["id"]) for s, a, b in want_pairs]
+        assert await akb.retrieve_many([], 3) == []
+        # the reference's own pair test (tests/test_kb.py:1254-1263 async twin): counts clamp
+        assert len(await akb.document_top_pairwise_scores(10 ** 6)) == 100 * 99 // 2
+        async with akb.bulk_add_docs() as add_doc:          # an add between two batched searches
+            await add_doc("doc 120")
+        after = await akb.retrieve_many(["doc 120", "doc 5"], 3)
+        assert after[0][0]["doc"]["text"] == "doc 120" and abs(after[0][0]["score"] - 1.0) < 1e-5
+        await akb.close()
+
+    asyncio.run(run())
+    assert OracleIndex.live == 0
+
+
 def test_incremental_add_and_delete_edit_the_loaded_matrix(tmp_path):
     """bulk_add_docs / bulk_del_docs on a LOADED KB append / tombstone rows of the
     HBM copy instead of dropping it; results must equal a KB
