@@ -121,8 +121,10 @@ def test_async_kb_retrieve_many_and_pairs_on_hip(gpu, tmp_path):
         got_many, got_pairs = await asyncio.gather(akb.retrieve_many(qs, 9), akb.document_top_pairwise_scores(50))
         assert got_many == want_many
         assert [(s, a["id"], b["id"]) for s, a, b in got_pairs] == [(s, a["id"], b["id"]) for s, a, b in want_pairs]
-        for i in (0, 5, len(qs) - 1):
-            assert await akb.retrieve(qs[i], 9) == got_many[i]
+        for i in (0, 5, len(qs) - 1):     # (single-query GEMV vs batched MFMA kernel: other summation order)
+            one = await akb.retrieve(qs[i], 9)
+            assert [d["doc"]["id"] for d in one] == [d["doc"]["id"] for d in got_many[i]]
+            assert max(abs(a["score"] - b["score"]) for a, b in zip(one, got_many[i])) <= 1e-5
         await akb.close()
 
     asyncio.run(run())
