@@ -123,6 +123,22 @@ int32_t svs_index_append_from_device(svs_index* idx, const float* dev_rows, int6
  * from SELECT COUNT(*) up front the same way (src/svs/kb.py:574-601). */
 int32_t svs_index_reserve(svs_index* idx, int64_t rows_capacity);
 
+/* ---- cold start without a host matrix: replaces the row loop of _Querier.build_embeddings_matrix,
+ *      src/svs/kb.py:603-615 (98.7 s per 1M rows published) ---------------
+ * The caller decodes SQLite BLOBs (little-endian f32, src/svs/embeddings/util.py:15-23) STRAIGHT
+ * into pinned staging memory owned by the library and commits block after block; the DMA of block i
+ * overlaps the filling of block i + 1 (two 32 MiB blocks).  No (n, m) host matrix, no second host
+ * copy.  One producer at a time per handle; searches issued before svs_index_staging_finish() wait
+ * for the pending copies first.
+ *   acquire: a pinned block of *rows_cap rows x d floats the caller may fill (blocks until the DMA
+ *            that last read this block has finished);
+ *   commit:  appends the first n_rows rows of the block last acquired behind the existing rows
+ *            (as svs_index_append) and returns once the copy is ENQUEUED;
+ *   finish:  waits for every pending copy and frees the staging blocks. */
+int32_t svs_index_staging_acquire(svs_index* idx, float** host_block, int64_t* rows_cap);
+int32_t svs_index_staging_commit(svs_index* idx, int64_t n_rows);
+int32_t svs_index_staging_finish(svs_index* idx);
+
 /* Tombstones rows (GLOBAL indices, i.e. row_offset + local): they keep their index
  * (later rows do not shift, so the caller's emb_id_lookup stays valid) but can never
  * be returned again; count = min(k, n - masked).  Relative order of the surviving rows

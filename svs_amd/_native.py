@@ -59,6 +59,9 @@ SIGNATURES = {
     "svs_index_append": (C.c_int32, [_P, _P, C.c_int64]),
     "svs_index_append_from_device": (C.c_int32, [_P, _P, C.c_int64, C.c_int64]),
     "svs_index_reserve": (C.c_int32, [_P, C.c_int64]),
+    "svs_index_staging_acquire": (C.c_int32, [_P, C.POINTER(_P), C.POINTER(C.c_int64)]),
+    "svs_index_staging_commit": (C.c_int32, [_P, C.c_int64]),
+    "svs_index_staging_finish": (C.c_int32, [_P]),
     "svs_index_mask_rows": (C.c_int32, [_P, _P, C.c_int64]),
     "svs_index_retain": (C.c_int32, [_P]),
     "svs_index_release": (C.c_int32, [_P]),

@@ -109,6 +109,19 @@ struct svs_index {
   int n_ctx = 0;
   static constexpr int kMaxCtx = 8;
 
+  // cold-start staging (svs_index_staging_*): two pinned blocks, DMA'd on their own stream
+  struct Staging {
+    void* pin[2] = {nullptr, nullptr};
+    float* dstage[2] = {nullptr, nullptr};   // f16 / fp8: the f32 block lands here, a kernel converts it
+    hipEvent_t done[2] = {nullptr, nullptr};
+    hipStream_t st = nullptr;
+    int cur = 1;                             // block handed out by the last acquire
+    int64_t rows_cap = 0;
+    bool active = false;
+  } stg;
+  std::mutex stg_mu;
+  std::atomic<bool> staging_pending{false};
+
   std::atomic<int> timing{0};          // 0 off, N: time every N-th search
   std::atomic<uint32_t> timing_seq{0};
   std::atomic<int> variant{0};
@@ -140,8 +153,24 @@ void ctx_destroy(Ctx* c) {
   delete c;
 }
 
+void staging_free(svs_index* idx) {
+  auto& g = idx->stg;
+  if (g.st) (void)hipStreamSynchronize(g.st);
+  for (int i = 0; i < 2; ++i) {
+    if (g.pin[i]) (void)hipHostFree(g.pin[i]);
+    if (g.dstage[i]) (void)hipFree(g.dstage[i]);
+    if (g.done[i]) (void)hipEventDestroy(g.done[i]);
+    g.pin[i] = nullptr; g.dstage[i] = nullptr; g.done[i] = nullptr;
+  }
+  if (g.st) (void)hipStreamDestroy(g.st);
+  g.st = nullptr;
+  g.active = false;
+  idx->staging_pending.store(false);
+}
+
 void index_destroy(svs_index* idx) {
   (void)hipSetDevice(idx->device);
+  staging_free(idx);
   for (Ctx* c : idx->free_ctx) ctx_destroy(c);
   for (auto& t : idx->evs) {
     (void)hipEventDestroy(t.e0);
@@ -752,6 +781,11 @@ int enqueue_search(svs_index* idx, Ctx* c, const float* q_dev, int nq, int k, in
                    float* out_s, int64_t* out_r, hipStream_t st, bool allow_fused = false) {
   const int64_t n = idx->n;
   int rc;
+  if (idx->staging_pending.load()) {   // rows committed by svs_index_staging_commit may still be in flight
+    std::lock_guard<std::mutex> lk(idx->stg_mu);
+    if (idx->stg.st) HIP_TRY(hipStreamSynchronize(idx->stg.st));
+    idx->staging_pending.store(false);
+  }
   const bool path_a = k > 0 && n > SORT_CAP && count <= SEL_KMAX;
   // Fused top-k epilogue (no score matrix) for the batched kernels; a query whose
   // candidate list overflows comes back marked and is re-run by the caller.  The prefix
@@ -1157,6 +1191,82 @@ int32_t svs_index_append_from_device(svs_index* idx, const float* dev_rows, int6
   idx->n = n_tot;
   idx->dead_flag.resize((size_t)n_tot, 0);
   return sync_dead_bits(idx);
+}
+
+int32_t svs_index_staging_acquire(svs_index* idx, float** host_block, int64_t* rows_cap) {
+  if (!idx || !host_block || !rows_cap) return fail(SVS_ERR_INVALID, "null argument");
+  if (idx->d == 0) return fail(SVS_ERR_SHAPE, "cannot stage rows of a zero-dimensional index");
+  HIP_TRY(hipSetDevice(idx->device));
+  std::lock_guard<std::mutex> lk(idx->stg_mu);
+  auto& g = idx->stg;
+  if (!g.active) {
+    const size_t row_b = (size_t)idx->d * sizeof(float);
+    g.rows_cap = (int64_t)std::max<size_t>(1, ((size_t)32 << 20) / row_b);
+    HIP_TRY(hipStreamCreateWithFlags(&g.st, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+      HIP_TRY(hipHostMalloc(&g.pin[i], (size_t)g.rows_cap * row_b, hipHostMallocDefault));
+      HIP_TRY(hipEventCreateWithFlags(&g.done[i], hipEventDisableTiming));
+      if (idx->dtype != SVS_DTYPE_F32) HIP_TRY(hipMalloc((void**)&g.dstage[i], (size_t)g.rows_cap * row_b));
+    }
+    g.cur = 1;
+    g.active = true;
+  }
+  g.cur ^= 1;
+  HIP_TRY(hipEventSynchronize(g.done[g.cur]));   // the DMA that last read this block (never recorded: returns at once)
+  *host_block = (float*)g.pin[g.cur];
+  *rows_cap = g.rows_cap;
+  return SVS_OK;
+}
+
+int32_t svs_index_staging_commit(svs_index* idx, int64_t n_rows) {
+  if (!idx) return fail(SVS_ERR_INVALID, "null index");
+  if (n_rows < 0) return fail(SVS_ERR_INVALID, "negative row count");
+  if (n_rows == 0) return SVS_OK;
+  std::unique_lock<std::shared_mutex> geo(idx->rw);
+  std::lock_guard<std::mutex> lk(idx->stg_mu);
+  auto& g = idx->stg;
+  if (!g.active) return fail(SVS_ERR_INVALID, "svs_index_staging_commit without svs_index_staging_acquire");
+  if (n_rows > g.rows_cap) return fail(SVS_ERR_INVALID, "%lld rows do not fit the staging block (%lld)", (long long)n_rows, (long long)g.rows_cap);
+  HIP_TRY(hipSetDevice(idx->device));
+  const int64_t n_old = idx->n, n_tot = n_old + n_rows;
+  if (n_tot > idx->cap) {   // growing reallocates: drain our own copies first (ensure_capacity drains the rest)
+    HIP_TRY(hipStreamSynchronize(g.st));
+    int rc = ensure_capacity(idx, n_tot, false);
+    if (rc != SVS_OK) return rc;
+  }
+  const int d = idx->d, b = g.cur;
+  const size_t row_b = (size_t)d * sizeof(float);
+  if (idx->dtype == SVS_DTYPE_F32) {
+    float* dst = (float*)idx->rows + (size_t)n_old * idx->ld;
+    if (idx->ld == d) HIP_TRY(hipMemcpyAsync(dst, g.pin[b], (size_t)n_rows * row_b, hipMemcpyHostToDevice, g.st));
+    else {
+      HIP_TRY(hipMemsetAsync(dst, 0, (size_t)n_rows * idx->ld * sizeof(float), g.st));
+      HIP_TRY(hipMemcpy2DAsync(dst, (size_t)idx->ld * sizeof(float), g.pin[b], row_b, row_b, (size_t)n_rows, hipMemcpyHostToDevice, g.st));
+    }
+  } else {
+    HIP_TRY(hipMemcpyAsync(g.dstage[b], g.pin[b], (size_t)n_rows * row_b, hipMemcpyHostToDevice, g.st));
+    if (idx->dtype == SVS_DTYPE_F16)
+      hipLaunchKernelGGL(convert_rows_f16_kernel, dim3(2048), dim3(256), 0, g.st, (const float*)g.dstage[b], n_rows, d, (int64_t)d,
+                         (_Float16*)idx->rows + (size_t)n_old * idx->ld, idx->ld);
+    else
+      hipLaunchKernelGGL(quantize_rows_fp8_kernel, dim3(2048), dim3(256), 0, g.st, (const float*)g.dstage[b], n_rows, d, (int64_t)d,
+                         (uint8_t*)idx->rows + (size_t)n_old * idx->ld, idx->ld, idx->row_scales + n_old, (float*)nullptr);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipEventRecord(g.done[b], g.st));
+  idx->staging_pending.store(true);
+  idx->n = n_tot;
+  idx->dead_flag.resize((size_t)n_tot, 0);
+  return sync_dead_bits(idx);
+}
+
+int32_t svs_index_staging_finish(svs_index* idx) {
+  if (!idx) return fail(SVS_ERR_INVALID, "null index");
+  HIP_TRY(hipSetDevice(idx->device));
+  std::lock_guard<std::mutex> lk(idx->stg_mu);
+  if (idx->stg.st) HIP_TRY(hipStreamSynchronize(idx->stg.st));
+  staging_free(idx);
+  return SVS_OK;
 }
 
 int32_t svs_index_mask_rows(svs_index* idx, const int64_t* rows, int64_t count) {

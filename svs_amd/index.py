@@ -153,6 +153,22 @@ class DeviceIndex:
             self._handle(), C.c_void_p(ptr), int(n), int(src_ld if src_ld is not None else self.d)))
         self._refresh()
 
+    # -- cold start: BLOBs decoded straight into the library's pinned staging blocks --------------
+    def staging_acquire(self) -> np.ndarray:
+        """A (rows_cap, d) float32 array over pinned memory owned by the library: fill its first rows,
+        then ``staging_commit(n)``.  Two blocks alternate; the DMA of one overlaps the filling of the other."""
+        ptr, cap = C.c_void_p(), C.c_int64(0)
+        _native.check(self._lib.svs_index_staging_acquire(self._handle(), C.byref(ptr), C.byref(cap)))
+        buf = (C.c_float * (cap.value * self.d)).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=np.float32).reshape(cap.value, self.d)
+
+    def staging_commit(self, n_rows: int) -> None:
+        _native.check(self._lib.svs_index_staging_commit(self._handle(), int(n_rows)))
+
+    def staging_finish(self) -> None:
+        _native.check(self._lib.svs_index_staging_finish(self._handle()))
+        self._refresh()
+
     def mask_rows(self, rows) -> None:
         """Tombstone rows (global indices): they are never returned again; the other
         rows keep their indices."""

@@ -202,10 +202,62 @@ class _Store:
         assert i == n - 1
         return matrix, lookup
 
+    def embedding_blocks(self, block_bytes: int = 32 << 20, acquire=None):
+        """The same rows as ``build_embeddings_matrix`` without the (n, m) host matrix: yields
+        (n, m) first, then (ids i64[r], rows f32[r, m]) blocks of ~32 MiB -- the size of the library's
+        pinned staging chunks -- each BLOB byte-copied into the block through a memoryview.  The
+        consumer appends every block to the HBM copy (svs_index_append) before asking for the next,
+        so the host never holds more than one block of a 6 GB (1M x 1536) corpus.  The block buffer is
+        reused: copy what you keep.  With ``acquire`` every block is decoded into the (cap, m) f32
+        array that call returns (asked for again after each yield) instead of a private buffer."""
+        n = int(self.conn.execute("SELECT COUNT(*) FROM embeddings").fetchone()[0])
+        first = self.conn.execute("SELECT embedding FROM embeddings LIMIT 1").fetchone()
+        m = len(first[0]) // 4 if first is not None else 0
+        yield n, m
+        if n * m == 0:
+            return
+        assert sys.byteorder == "little"
+        rb = m * 4
+
+        def fresh():
+            b = acquire() if acquire is not None else np.empty((max(1, block_bytes // rb), m), dtype=np.float32)
+            assert b.dtype == np.float32 and b.ndim == 2 and b.shape[1] == m and b.flags["C_CONTIGUOUS"]
+            return b, memoryview(b).cast("B")
+
+        buf, raw = fresh()
+        cap = buf.shape[0]
+        ids = np.empty(cap, dtype=np.int64)
+        fill = total = 0
+        for emb_id, blob in self.conn.execute("SELECT id, embedding FROM embeddings"):
+            assert len(blob) == rb
+            raw[fill * rb:(fill + 1) * rb] = blob
+            ids[fill] = emb_id
+            fill += 1
+            if fill == cap:
+                yield ids[:fill], buf[:fill]
+                total += fill
+                fill = 0
+                if acquire is not None:      # the consumer has committed the block: take the other one
+                    buf, raw = fresh()
+                    assert buf.shape[0] == cap
+        if fill:
+            yield ids[:fill], buf[:fill]
+            total += fill
+        assert total == n
+
 
 def _build_from_store(store: _Store) -> Tuple[np.ndarray, np.ndarray]:
     with store.transaction():
         return store.build_embeddings_matrix()
+
+
+def _blocks_from_store(store: _Store, acquire=None):
+    """Streaming form of the cold start: first (n, m), then (ids, rows)
+    blocks in ``SELECT id, embedding FROM embeddings`` order, inside one read transaction.
+    ``acquire()`` (optional) supplies the block to decode into -- the library's pinned staging
+    memory (DeviceIndex.staging_acquire) -- so a BLOB's bytes are copied exactly once on the host."""
+    with store.transaction():
+        yield from store.embedding_blocks(acquire=acquire)
 
 
 class KB:
@@ -222,7 +274,8 @@ class KB:
             import functools
             index_factory = functools.partial(index_factory, dtype=dtype)
         self.embeddings_matrix = DeviceEmbeddingsMatrix(device=device, builder=_build_from_store,
-                                                        index_factory=index_factory, keep_host_matrix=False)
+                                                        index_factory=index_factory, keep_host_matrix=False,
+                                                        block_builder=_blocks_from_store)
         self._loop = asyncio.new_event_loop()
 
     # -- embedding helpers (A8) -------------------------------------------------
@@ -387,7 +440,8 @@ class AsyncKB:
             import functools
             index_factory = functools.partial(index_factory, dtype=dtype)
         self.embeddings_matrix = DeviceEmbeddingsMatrix(device=device, builder=_build_from_store,
-                                                        index_factory=index_factory, keep_host_matrix=False)
+                                                        index_factory=index_factory, keep_host_matrix=False,
+                                                        block_builder=_blocks_from_store)
 
     def _get_lock(self) -> asyncio.Lock:
         if self._lock is None:

@@ -59,9 +59,13 @@ class DeviceEmbeddingsMatrix:
 
     def __init__(self, device: int = 0, builder: MatrixBuilder = _default_builder,
                  index_factory: Callable[..., Any] = DeviceIndex, keep_host_matrix: bool = True,
-                 view: bool = False):
+                 view: bool = False, block_builder: Optional[Callable[[Any], Any]] = None):
         self.device = device
         self._builder = builder
+        # optional streaming producer: db -> iterator of (n, m), then (ids, rows) blocks
+        # (svs_amd.kb._blocks_from_store); used when no host copy is kept and the index type can
+        # start empty and grow (DeviceIndex.empty / append)
+        self._block_builder = block_builder
         self._index_factory = index_factory
         self._keep_host = keep_host_matrix
         self._view = view
@@ -88,6 +92,63 @@ class DeviceEmbeddingsMatrix:
             self._n_dead = 0
         if idx is not None:
             idx.release()
+
+    def _empty_factory(self):
+        """(d, reserve) -> an empty index of the configured type, or None if the type cannot grow
+        from nothing (test doubles, MultiDeviceIndex)."""
+        f, kw = self._index_factory, {}
+        if hasattr(f, "func") and hasattr(f, "keywords"):     # functools.partial(DeviceIndex, dtype=...)
+            f, kw = f.func, dict(f.keywords)
+        make = getattr(f, "empty", None)
+        if make is None:
+            return None
+        return lambda d, reserve: make(d, device=self.device, reserve=reserve, **kw)
+
+    def _build_and_install(self, db):
+        """Cold start (src/svs/kb.py:573-618 + :875-876).  Streaming when possible: BLOB -> 32 MiB
+        block -> svs_index_append (pinned staging, DMA overlapped with the next block's copy) -- the
+        reference's (n, m) host matrix is never materialised; otherwise matrix-then-upload."""
+        make = self._empty_factory() if (self._block_builder is not None and not self._keep_host) else None
+        if make is None:
+            matrix, lookup = self._builder(db)
+            return self._install(matrix, lookup)
+        holder: dict = {}
+        # blocks are decoded straight into the library's pinned staging memory when the index offers it
+        acquire = (lambda: holder["idx"].staging_acquire()) if hasattr(getattr(self._index_factory, "func", self._index_factory),
+                                                                        "staging_acquire") else None
+        try:
+            blocks = self._block_builder(db, acquire=acquire)
+        except TypeError:            # a block builder without the `acquire` hook
+            acquire = None
+            blocks = self._block_builder(db)
+        n, m = next(blocks)
+        if n * m == 0:
+            for _ in blocks:
+                pass
+            return self._install(np.zeros((n, m), dtype=np.float32), np.zeros(n, dtype=np.int64))
+        idx = holder["idx"] = make(m, n)
+        ids_all = np.empty(n, dtype=np.int64)
+        fill = 0
+        try:
+            for ids, rows in blocks:
+                if acquire is not None:
+                    idx.staging_commit(len(ids))      # DMA enqueued; the next block is decoded meanwhile
+                else:
+                    idx.append(rows)                  # copies out of the reused block before returning
+                ids_all[fill:fill + len(ids)] = ids
+                fill += len(ids)
+            if acquire is not None:
+                idx.staging_finish()
+            assert fill == n and idx.shape == (n, m)
+        except BaseException:
+            idx.release()
+            raise
+        with self._mu:
+            self.index = idx
+            self._lookup = _Lookup(ids_all)
+            self._n_dead = 0
+            self.embeddings_matrix = None
+        return idx
 
     def _install(self, matrix: np.ndarray, lookup: np.ndarray):
         idx = self._index_factory(matrix, device=self.device)
@@ -160,8 +221,7 @@ class DeviceEmbeddingsMatrix:
             _LOG.info("using cached vectors")
             return self._result()
         _LOG.info("re-building cached vectors...")
-        matrix, lookup = self._builder(db)
-        self._install(matrix, lookup)
+        self._build_and_install(db)
         _LOG.info("re-building cached vectors... DONE!")
         return self._result()
 
@@ -172,8 +232,7 @@ class DeviceEmbeddingsMatrix:
             return self._result()
         _LOG.info("re-building cached vectors...")
         loop = asyncio.get_running_loop()
-        matrix, lookup = await loop.run_in_executor(None, lambda: self._builder(db))
-        await loop.run_in_executor(None, lambda: self._install(matrix, lookup))
+        await loop.run_in_executor(None, lambda: self._build_and_install(db))
         _LOG.info("re-building cached vectors... DONE!")
         return self._result()
 

@@ -128,3 +128,56 @@ def test_async_kb_retrieve_many_and_pairs_on_hip(gpu, tmp_path):
         await akb.close()
 
     asyncio.run(run())
+
+
+@pytest.mark.parametrize("dtype,d", [("f32", 2048), ("f16", 2048), ("fp8", 2048), ("f32", 1000)])
+def test_streaming_cold_start_equals_matrix_upload(gpu, tmp_path, dtype, d):
+    """KB.load() decodes BLOBs straight into the library's pinned staging blocks and commits them
+    (svs_index_staging_acquire / commit / finish: no (n, m) host matrix, one host copy per byte): the
+    index must hold exactly what DeviceIndex(build_embeddings_matrix()) holds, ids included
+    (non-contiguous after a delete).  d = 2048: a staging block holds 4,096 rows, so 4,500 rows take two
+    blocks; d = 1000: rows padded to ld = 1,024 in HBM (the 2-D copy)."""
+    import svs_amd
+    from svs_amd import DeviceIndex
+    n = 4500
+    rng = np.random.default_rng(5)
+    vecs = rng.standard_normal((n, d)).astype(np.float32)
+    vecs /= np.linalg.norm(vecs, axis=1, keepdims=True)
+    path = str(tmp_path / f"cold_{dtype}_{d}.sqlite")
+    from svs_amd.kb import _Store
+    st = _Store(path)                                  # written directly: 9M python floats through an embedding func would take minutes
+    with st.transaction():
+        st.conn.executemany("INSERT INTO embeddings (embedding) VALUES (?)", [(r.tobytes(),) for r in vecs])
+        st.conn.executemany("INSERT INTO docs (parent_id, level, text, embedding, meta) VALUES (NULL, 0, ?, ?, NULL)",
+                            [(f"doc {i}", i + 1) for i in range(n)])
+        st.del_doc(7); st.del_doc(n)
+    st.close()
+
+    async def ef(texts):
+        return [[float(x) for x in vecs[int(t.split()[1])]] for t in texts]
+
+    kb = svs_amd.KB(path, ef, dtype=dtype)             # cold
+    kb.load()
+    with kb.db.transaction():
+        m, lk = kb.db.build_embeddings_matrix()
+    assert m.shape == (n - 2, d)
+    assert kb.embeddings_matrix.embeddings_matrix is None                # no host copy kept
+    assert np.array_equal(kb.embeddings_matrix.emb_id_lookup, lk) and 7 not in lk and 1 in lk
+    ref = DeviceIndex(m, dtype=dtype)
+    idx = kb.embeddings_matrix.index
+    assert idx.shape == ref.shape
+    assert np.array_equal(idx.stored_rows(), ref.stored_rows())
+    if dtype == "fp8":
+        q = vecs[1234]
+        assert idx.search(q, 10) == ref.search(q, 10)                    # row scales too
+    docs = kb.retrieve("doc 1234", 5)
+    assert docs[0]["doc"]["text"] == "doc 1234"
+    # a search issued right after the last commit waits for the pending copies itself
+    idx2 = DeviceIndex.empty(d, dtype=dtype, reserve=100)
+    blk = idx2.staging_acquire()
+    blk[:50] = vecs[:50]
+    idx2.staging_commit(50)
+    assert idx2.search(vecs[3], 1)[0][1] == 3
+    idx2.staging_finish()
+    assert idx2.shape == (50, d)
+    idx2.release(); ref.release(); kb.close()

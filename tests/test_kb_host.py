@@ -243,3 +243,32 @@ def test_attach_to_the_real_reference_kb(tmp_path):
         sys.path.remove("/root/reference/src")
         for k in [k for k in sys.modules if k == "svs" or k.startswith("svs.")]:
             del sys.modules[k]
+
+
+def test_embedding_blocks_equal_the_matrix_build(tmp_path):
+    """Streaming cold start: the (ids, rows) blocks are exactly the rows of
+    build_embeddings_matrix (reference src/svs/kb.py:573-618; KATs tests/test_kb.py:753-806), whatever the
+    block size; the empty table gives (0, 0) and no block."""
+    from svs_amd.kb import _Store, embedding_to_bytes
+    st = _Store(str(tmp_path / "blocks.sqlite"))
+    with st.transaction():
+        assert list(st.embedding_blocks()) == [(0, 0)]
+    rng = np.random.default_rng(0)
+    vecs = rng.standard_normal((1000, 12)).astype(np.float32)
+    with st.transaction():
+        for i, v in enumerate(vecs):
+            d = st.add_doc(f"doc {i}", None, None)
+            st.set_doc_embedding(d, embedding_to_bytes([float(x) for x in v]))
+        st.del_doc(4); st.del_doc(777)                      # ids are not contiguous after deletes
+    with st.transaction():
+        m, lk = st.build_embeddings_matrix()
+    for block_bytes in (48, 12 * 4 * 7, 1 << 20):
+        with st.transaction():
+            it = st.embedding_blocks(block_bytes)
+            assert next(it) == m.shape
+            ids, rows = [], []
+            for a, b in it:
+                assert len(a) * 12 * 4 <= max(block_bytes, 48)
+                ids.append(a.copy()); rows.append(b.copy())   # the block buffer is reused
+        assert np.array_equal(np.concatenate(ids), lk) and np.array_equal(np.vstack(rows), m)
+    st.close()
