@@ -185,8 +185,13 @@ int32_t svs_index_scores(svs_index* idx, const float* query, int32_t d, float* o
  *      document_top_pairwise_scores, src/svs/kb.py:1642-1671, src/svs/util.py:206-233 --
  * The k best-scoring row PAIRS (i < j; diagonal and lower triangle ignored), ordered
  * (score desc, then i desc, then j desc -- the reference's flat upper-triangle index,
- * descending).  count = min(max(k,0), n(n-1)/2).  The n x n score matrix is
- * materialised in HBM like the reference materialises it in RAM; n*n <= 2^32. */
+ * descending).  count = min(max(k,0), n(n-1)/2).  Up to n*n = 2^32 scores (65,536 rows) the
+ * n x n matrix is materialised in HBM like the reference materialises it in RAM.  Beyond that
+ * nothing of that size exists: the exact k-th best pair score of a prefix block bounds the
+ * answer from below, the tiled MFMA GEMM runs with the i < j mask and that bound in its
+ * epilogue, and only the surviving pairs are ordered (same order key, same result).  Needs rows
+ * of whole 128-byte lines there; SVS_ERR_UNSUPPORTED if millions of pairs pass the bound
+ * (near-duplicate documents en masse) or k needs a prefix block past 2^32 scores. */
 int32_t svs_index_top_pairs(svs_index* idx, int32_t k, float* out_scores, int64_t* out_i, int64_t* out_j,
                             int32_t* out_count);
 

@@ -80,6 +80,16 @@ __device__ __forceinline__ void fuse_offer(uint32_t* hdr, uint64_t* cand, uint32
   if (slot < cap) cand[slot] = ((uint64_t)score_key(v) << 32) | row;
 }
 
+// Pair mode of the fused epilogue (svs_index_top_pairs on corpora too large to materialise n x n
+// scores; reference src/svs/util.py:206-233 keeps the strict upper triangle i < j): the queries of
+// a launch ARE corpus rows query_row0 .. (global), the row operand starts at global row row_base,
+// and a score is a candidate only for global row > the query's own row (and only for queries from
+// first_query on: the last query chunk overlaps the one before it).
+struct TgPairs {
+  long long query_row0 = 0, row_base = 0, first_query = 0;
+  int on = 0;
+};
+
 // ---- epilogue shared by gemm_tiled_kernel and gemm_phased_kernel ------------------------
 // acc[i][j] = one 16 x 16 f32 tile of the wave: rows row0 + wrow + 16 i + 4 g + r (r = register),
 // query q0 + wq + 16 j + (lane & 15).  FUSE == false: scores [nq][sstride] are written.
@@ -91,7 +101,8 @@ __device__ __forceinline__ void tg_epilogue(f32x4_t (&acc)[MT][NT], int64_t row0
                                             uint32_t* __restrict__ fstate_words, int fstate_stride,
                                             uint64_t* __restrict__ fcand, uint32_t fcap,
                                             const float* __restrict__ fthr, int fthr_stride,
-                                            const float* __restrict__ rscale, const float* __restrict__ qscale) {
+                                            const float* __restrict__ rscale, const float* __restrict__ qscale,
+                                            const TgPairs pairs = TgPairs{}) {
   const int r16 = lane & 15, g = lane >> 4;
   // fp8: the lane's MT * 4 row scales, fetched once (they are the same for every query tile)
   f32x4_t rs[EB == 1 ? MT : 1];
@@ -123,31 +134,40 @@ __device__ __forceinline__ void tg_epilogue(f32x4_t (&acc)[MT][NT], int64_t row0
         // Interior tiles (all but the last row tile) skip the row-bound checks.
         const float thr = fthr[(int64_t)query * fthr_stride];
         const int lr0 = wrow + 4 * g;                          // the lane's first row inside the tile
-        const int lim = (int)(n - row0 < BM ? n - row0 : BM);  // live rows of this tile
+        int lim = (int)(n - row0 < BM ? n - row0 : BM);        // live rows of this tile
+        // pair mode: only rows ABOVE the query's own row count (first local row that does: plo)
+        int plo = 0;
+        if (pairs.on) {
+          const long long qrow = pairs.query_row0 + query;
+          const long long first = qrow + 1 - (pairs.row_base + row0);
+          plo = first > BM ? BM : (first < 0 ? 0 : (int)first);
+          if (qrow < pairs.first_query) plo = BM;
+        }
         auto offer = [&](auto FULL) {
           constexpr bool full = decltype(FULL)::value;
           uint32_t cnt = 0;
 #pragma unroll
           for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) cnt += (!(acc[i][j][r] < thr) && (full || lr0 + i * 16 + r < lim)) ? 1u : 0u;
+            for (int r = 0; r < 4; ++r)
+              cnt += (!(acc[i][j][r] < thr) && (full || (lr0 + i * 16 + r < lim && lr0 + i * 16 + r >= plo))) ? 1u : 0u;
           if (cnt) {
             uint32_t slot = atomicAdd(fstate_words + (int64_t)query * fstate_stride, cnt);
             uint64_t* cq = fcand + (int64_t)query * fcap;
-            const uint32_t row_lo = (uint32_t)(row0 + lr0);
+            const uint32_t row_lo = (uint32_t)(pairs.row_base + row0 + lr0);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 const float v = acc[i][j][r];
-                if (!(v < thr) && (full || lr0 + i * 16 + r < lim)) {
+                if (!(v < thr) && (full || (lr0 + i * 16 + r < lim && lr0 + i * 16 + r >= plo))) {
                   if (slot < fcap) cq[slot] = ((uint64_t)score_key(v) << 32) | (row_lo + (uint32_t)(i * 16 + r));
                   ++slot;
                 }
               }
           }
         };
-        if (lim == BM) offer(std::true_type{});
+        if (lim == BM && plo == 0) offer(std::true_type{});
         else offer(std::false_type{});
       } else {
         float* o = scores + (int64_t)query * sstride;
@@ -216,7 +236,7 @@ __global__ __launch_bounds__(TG_WAVES * 64) void gemm_tiled_kernel(
     const uint8_t* __restrict__ M, const uint8_t* __restrict__ Q, float* __restrict__ scores,
     int64_t n, int64_t ldb, int64_t sstride, int nq, uint32_t* __restrict__ fstate_words, int fstate_stride,
     uint64_t* __restrict__ fcand, uint32_t fcap, const float* __restrict__ fthr, int fthr_stride,
-    const float* __restrict__ rscale, const float* __restrict__ qscale) {
+    const float* __restrict__ rscale, const float* __restrict__ qscale, const TgPairs pairs = TgPairs{}) {
   constexpr int TN = BN < 64 ? BN : 64;     // queries per wave tile
   constexpr int WN = BN / TN;               // waves along the query axis
   constexpr int WM = TG_WAVES / WN;         // waves along the row axis
@@ -394,7 +414,7 @@ __global__ __launch_bounds__(TG_WAVES * 64) void gemm_tiled_kernel(
 
   TG_STAMP_BLOCK(2);
   tg_epilogue<FUSE, EB, MT, NT, BM>(acc, row0, q0, wm * TM, wn * TN, lane, n, nq, scores, sstride, fstate_words, fstate_stride,
-                                    fcand, fcap, fthr, fthr_stride, rscale, qscale);
+                                    fcand, fcap, fthr, fthr_stride, rscale, qscale, pairs);
   TG_STAMP_BLOCK(3);
 }
 

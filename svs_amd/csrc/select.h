@@ -502,6 +502,42 @@ __global__ void mask_upper_triangle_kernel(float* __restrict__ S, int64_t n, int
   }
 }
 
+// ---- pairwise path on large corpora: per-query candidate lists -> one global pair list ----------
+// After a pair-mode GEMM over one chunk of query rows (gemm_tiled.h, TgPairs) every query q of the
+// chunk has its candidates (score key << 32 | global row j, j > i) in cand[q][0 .. n_cand).  This
+// kernel appends them as (score key, i, j) to the global list, drops pairs with a tombstoned row,
+// flags a query whose list overflowed, and zeroes the query's header for the next chunk.
+// grid = queries of the chunk.  gstate: [0] = pairs appended (may exceed cap), [1] = overflow flag.
+__global__ __launch_bounds__(256) void collect_pairs_kernel(
+    uint32_t* __restrict__ scratch, const uint64_t* __restrict__ cand, long long query_row0, long long first_query,
+    const uint32_t* __restrict__ dead_bits, uint32_t* __restrict__ gstate, uint32_t cap,
+    uint32_t* __restrict__ out_key, uint32_t* __restrict__ out_i, uint32_t* __restrict__ out_j) {
+  const int q = blockIdx.x;
+  SelHeader* hdr = (SelHeader*)(scratch + (int64_t)q * SCR_WORDS);
+  const uint32_t n_cand = hdr->n_cand;
+  const long long i = query_row0 + q;
+  __syncthreads();
+  if (threadIdx.x == 0) { hdr->n_cand = 0; hdr->flag = 0; }
+  if (i < first_query) return;
+  if (n_cand > (uint32_t)CAND_CAP) {
+    if (threadIdx.x == 0) atomicExch(&gstate[1], 1u);
+    return;
+  }
+  if (dead_bits && ((dead_bits[i >> 5] >> (i & 31)) & 1u)) return;
+  const uint64_t* cq = cand + (int64_t)q * CAND_CAP;
+  for (uint32_t c = threadIdx.x; c < n_cand; c += blockDim.x) {
+    const uint64_t key = cq[c];
+    const uint32_t j = (uint32_t)key;
+    if (dead_bits && ((dead_bits[j >> 5] >> (j & 31)) & 1u)) continue;
+    const uint32_t slot = atomicAdd(&gstate[0], 1u);
+    if (slot < cap) {
+      out_key[slot] = (uint32_t)(key >> 32);
+      out_i[slot] = (uint32_t)i;
+      out_j[slot] = j;
+    }
+  }
+}
+
 // ---- tombstones (svs_index_mask_rows) ------------------------------------------
 // scores[q][row] = -inf for every masked (tombstoned) row
 // (rows >= n_rows are skipped: the fused path materialises only a prefix of the corpus)
@@ -514,13 +550,15 @@ __global__ void mask_dead_rows_kernel(float* __restrict__ scores, int64_t sstrid
     if ((int64_t)r < n_rows) scores[q * sstride + r] = -__builtin_inff();
   }
 }
-// pairwise matrix S[n][np]: whole row and column of a masked row -> -inf
+// pairwise matrix S[n][np]: whole row and column of a masked row -> -inf (masked rows >= n: the
+// matrix covers a prefix of the corpus, nothing to do)
 __global__ void mask_dead_pairs_kernel(float* __restrict__ S, int64_t n, int64_t np,
                                        const uint32_t* __restrict__ dead, int64_t n_dead) {
   const int64_t total = n_dead * n;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
     const int64_t di = t / n, j = t - di * n;
     const int64_t r = dead[di];
+    if (r >= n) continue;
     S[r * np + j] = -__builtin_inff();
     S[j * np + r] = -__builtin_inff();
   }

@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <cstdarg>
@@ -514,9 +515,10 @@ struct FuseLaunch {   // non-null state: fused top-k epilogue, no score matrix
   uint64_t* cand = nullptr;
   const float* thr = nullptr;   // thr[q * thr_stride]: lower bound of query q's k-th best score
   int thr_stride = 0;
+  TgPairs pairs{};              // pair mode (svs_index_top_pairs, tiled kernels only): see gemm_tiled.h
   FuseLaunch at(int q0) const {
     if (!state) return *this;
-    return FuseLaunch{state + (size_t)q0 * SCR_WORDS, cand + (size_t)q0 * CAND_CAP, thr + (size_t)q0 * thr_stride, thr_stride};
+    return FuseLaunch{state + (size_t)q0 * SCR_WORDS, cand + (size_t)q0 * CAND_CAP, thr + (size_t)q0 * thr_stride, thr_stride, pairs};
   }
 };
 
@@ -598,10 +600,12 @@ int launch_tiled_bn(const svs_index* idx, Ctx* c, int64_t n_rows, int nq, float*
   });
   const unsigned gx = (unsigned)((n_rows + BM - 1) / BM), gy = (unsigned)((nq + BN - 1) / BN);
   const uint8_t* Q = EB == 2 ? (const uint8_t*)c->qh : (EB == 1 ? (const uint8_t*)c->q8 : (const uint8_t*)c->q_f32);
+  // pair mode: the row operand starts at global row fl.pairs.row_base (n_rows counts from there)
+  const int64_t rb = fl.pairs.on ? fl.pairs.row_base : 0;
   hipLaunchKernelGGL((gemm_tiled_kernel<BN, FUSE, EB, BM>), dim3(gx, gy), dim3(TG_WAVES * 64), lds, st,
-                     (const uint8_t*)idx->rows, Q, scores, n_rows, (int64_t)idx->ld * EB, sstride, nq,
+                     (const uint8_t*)idx->rows + (size_t)rb * idx->ld * EB, Q, scores, n_rows, (int64_t)idx->ld * EB, sstride, nq,
                      fl.state, (int)SCR_WORDS, fl.cand, (uint32_t)CAND_CAP, fl.thr, fl.thr_stride,
-                     (const float*)idx->row_scales, (const float*)c->q8s);
+                     (const float*)(idx->row_scales ? idx->row_scales + rb : nullptr), (const float*)c->q8s, fl.pairs);
   return SVS_OK;
 }
 
@@ -637,7 +641,7 @@ int launch_tiled_eb(const svs_index* idx, Ctx* c, int64_t n_rows, int nq, int bn
                     FuseLaunch fl, hipStream_t st) {
   const bool f = fl.state != nullptr;
   if constexpr (EB != 4) {
-    if (bn == 256 && phased_ok(idx, n_rows, nq))
+    if (bn == 256 && !fl.pairs.on && phased_ok(idx, n_rows, nq))
       return f ? launch_phased<true, EB>(idx, c, n_rows, nq, scores, sstride, fl, st)
                : launch_phased<false, EB>(idx, c, n_rows, nq, scores, sstride, fl, st);
   }
@@ -876,6 +880,166 @@ struct RefGuard {
   RefGuard(const RefGuard&) = delete;
   RefGuard& operator=(const RefGuard&) = delete;
 };
+
+// ---- pairwise (document_top_pairwise_scores, src/svs/kb.py:1642-1671) -----------------------
+// rows [r0, r0 + nrows) of the corpus as f32 queries (what the index holds), [nrows][d]
+int dequant_rows_to(svs_index* idx, int64_t r0, int64_t nrows, float* out, hipStream_t st) {
+  if (idx->dtype == SVS_DTYPE_F32)
+    HIP_TRY(hipMemcpy2DAsync(out, (size_t)idx->d * sizeof(float), (const float*)idx->rows + r0 * idx->ld, (size_t)idx->ld * sizeof(float),
+                             (size_t)idx->d * sizeof(float), (size_t)nrows, hipMemcpyDeviceToDevice, st));
+  else if (idx->dtype == SVS_DTYPE_F16)
+    hipLaunchKernelGGL(dequant_rows_f16_kernel, dim3(2048), dim3(256), 0, st, (const _Float16*)idx->rows, r0, nrows, idx->d, idx->ld, out);
+  else
+    hipLaunchKernelGGL(dequant_rows_fp8_kernel, dim3(2048), dim3(256), 0, st, (const uint8_t*)idx->rows, idx->row_scales, r0, nrows,
+                       idx->d, idx->ld, out);
+  return SVS_OK;
+}
+
+// Top `count` pairs among rows [0, ns) (ns * ns_padded <= 2^32): S = M M^T materialised, strict upper
+// triangle, the ordinary top-k stage over the flattened matrix (flat index i * np + j reproduces the
+// reference's tie order).  Results (scores, flat indices) stay on the device.
+int pairs_block_device(svs_index* idx, Ctx* c, int64_t ns, int count, float* S, float* qbuf, float* d_s, int64_t* d_r, hipStream_t st) {
+  const int64_t np = (ns + 3) & ~(int64_t)3;
+  int rc;
+  const int chunk = 1024;
+  for (int64_t q0 = 0; q0 < ns; q0 += chunk) {
+    const int nq = (int)std::min<int64_t>(chunk, ns - q0);
+    if ((rc = dequant_rows_to(idx, q0, nq, qbuf, st)) != SVS_OK) return rc;
+    if ((rc = launch_scores_any(idx, c, qbuf, ns, nq, S + q0 * np, np, FuseLaunch{}, st)) != SVS_OK) return rc;
+  }
+  hipLaunchKernelGGL(mask_upper_triangle_kernel, dim3(4096), dim3(256), 0, st, S, ns, np);
+  if (!idx->dead_list.empty())
+    hipLaunchKernelGGL(mask_dead_pairs_kernel, dim3(1024), dim3(256), 0, st, S, ns, np, idx->dead_dev, (int64_t)idx->dead_list.size());
+  const int64_t flat = ns * np;
+  const bool path_a = flat > SORT_CAP && count <= SEL_KMAX;
+  if (path_a && c->hist_cap < 1) {
+    HIP_TRY(hipMalloc((void**)&c->hist, (size_t)SCR_WORDS * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&c->cand, (size_t)CAND_CAP * sizeof(uint64_t)));
+    HIP_TRY(hipMemsetAsync(c->hist, 0, (size_t)SCR_WORDS * sizeof(uint32_t), st));
+    c->hist_cap = 1;
+  }
+  if ((rc = run_select(idx, c, S, flat, flat, 1, count, count, d_s, d_r, st, /*row_offset=*/0)) != SVS_OK) return rc;
+  HIP_TRY(hipGetLastError());
+  return SVS_OK;
+}
+
+struct DevTmp {   // frees on scope exit
+  std::vector<void*> p;
+  template <class T> hipError_t alloc(T** out, size_t bytes) {
+    hipError_t e = hipMalloc((void**)out, bytes);
+    if (e == hipSuccess) p.push_back((void*)*out);
+    return e;
+  }
+  ~DevTmp() { for (void* q : p) (void)hipFree(q); }
+};
+
+int top_pairs_materialised(svs_index* idx, Ctx* c, int64_t n, int count, float* out_scores, int64_t* out_i, int64_t* out_j) {
+  const int64_t np = (n + 3) & ~(int64_t)3;
+  hipStream_t st = c->stream;
+  DevTmp tmp;
+  float *qbuf = nullptr, *S = nullptr, *d_s = nullptr;
+  int64_t* d_r = nullptr;
+  HIP_TRY(tmp.alloc(&qbuf, (size_t)1024 * idx->d * sizeof(float)));
+  HIP_TRY(tmp.alloc(&S, (size_t)n * np * sizeof(float)));
+  HIP_TRY(tmp.alloc(&d_s, (size_t)count * sizeof(float)));
+  HIP_TRY(tmp.alloc(&d_r, (size_t)count * sizeof(int64_t)));
+  int rc = pairs_block_device(idx, c, n, count, S, qbuf, d_s, d_r, st);
+  if (rc != SVS_OK) return rc;
+  std::vector<int64_t> flat_rows((size_t)count);
+  HIP_TRY(hipMemcpyAsync(out_scores, d_s, (size_t)count * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(flat_rows.data(), d_r, (size_t)count * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  for (int t = 0; t < count; ++t) {
+    out_i[t] = flat_rows[t] / np + idx->row_offset;
+    out_j[t] = flat_rows[t] % np + idx->row_offset;
+  }
+  return SVS_OK;
+}
+
+// Corpora whose n x n scores cannot be materialised (n^2 > 2^32: beyond ~65k rows; the reference
+// itself stops at what fits its RAM).  (1) The exact count-th best pair score of a PREFIX block
+// (rows [0, P), materialised as above) is a lower bound of the global count-th best.  (2) The
+// tiled MFMA GEMM runs over chunks of query rows x the rows above them with the fused epilogue in
+// pair mode: scores >= that bound and j > i become per-query candidates, nothing else is written;
+// after each chunk they are appended to one global (score, i, j) list.  (3) The host orders the
+// list by (score desc, i desc, j desc) -- the reference's flat upper-triangle index, descending --
+// and keeps `count`.  Exact; the list holds about count * (n / P)^2 pairs.
+int top_pairs_tiled(svs_index* idx, Ctx* c, int count, float* out_scores, int64_t* out_i, int64_t* out_j) {
+  const int64_t n = idx->n;
+  if (!tiled_ok(idx)) return fail(SVS_ERR_UNSUPPORTED, "pairwise scores over %lld rows need rows of whole 128-byte lines (d = %d)", (long long)n, idx->d);
+  hipStream_t st = c->stream;
+  int rc;
+  // prefix block: at least `count` live pairs inside it
+  int64_t P = std::min<int64_t>(n, count > SEL_KMAX ? 8192 : 16384);
+  while (P < n && (P - (int64_t)idx->dead_list.size()) * (P - (int64_t)idx->dead_list.size() - 1) / 2 < count) P = std::min<int64_t>(n, P * 2);
+  const int64_t Pp = (P + 3) & ~(int64_t)3;
+  if (P * Pp > 0xffffffffll) return fail(SVS_ERR_UNSUPPORTED, "top_pairs: k = %d needs a prefix block past 2^32 scores", count);
+  constexpr int QC = 1024;                 // query rows per chunk
+  constexpr uint32_t LIST_CAP = 8u << 20;  // global pair list (96 MB)
+  DevTmp tmp;
+  float *qbuf = nullptr, *S = nullptr, *d_s = nullptr;
+  int64_t* d_r = nullptr;
+  uint32_t *gstate = nullptr, *l_key = nullptr, *l_i = nullptr, *l_j = nullptr;
+  HIP_TRY(tmp.alloc(&qbuf, (size_t)QC * idx->d * sizeof(float)));
+  HIP_TRY(tmp.alloc(&S, (size_t)P * Pp * sizeof(float)));
+  HIP_TRY(tmp.alloc(&d_s, (size_t)count * sizeof(float)));
+  HIP_TRY(tmp.alloc(&d_r, (size_t)count * sizeof(int64_t)));
+  HIP_TRY(tmp.alloc(&gstate, 16));
+  HIP_TRY(tmp.alloc(&l_key, (size_t)LIST_CAP * 4));
+  HIP_TRY(tmp.alloc(&l_i, (size_t)LIST_CAP * 4));
+  HIP_TRY(tmp.alloc(&l_j, (size_t)LIST_CAP * 4));
+  HIP_TRY(hipMemsetAsync(gstate, 0, 16, st));
+  if ((rc = pairs_block_device(idx, c, P, count, S, qbuf, d_s, d_r, st)) != SVS_OK) return rc;
+  const float* thr = d_s + (count - 1);    // the bound, read by the epilogue with stride 0
+  // per-query candidate scratch for one chunk
+  if ((size_t)QC > c->hist_cap) {
+    if (c->hist) HIP_TRY(hipFree(c->hist));
+    if (c->cand) HIP_TRY(hipFree(c->cand));
+    c->hist = nullptr; c->cand = nullptr; c->hist_cap = 0;
+    HIP_TRY(hipMalloc((void**)&c->hist, (size_t)QC * SCR_WORDS * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&c->cand, (size_t)QC * CAND_CAP * sizeof(uint64_t)));
+    HIP_TRY(hipMemsetAsync(c->hist, 0, (size_t)QC * SCR_WORDS * sizeof(uint32_t), st));
+    c->hist_cap = QC;
+  }
+  for (int64_t q0 = 0; q0 < n - 1; q0 += QC) {
+    // the last chunk is moved back so that it still holds QC rows (its first rows were done: first_query)
+    const int64_t qs = std::max<int64_t>(0, std::min<int64_t>(q0, n - QC));
+    const int nq = (int)std::min<int64_t>(QC, n - qs);
+    const int64_t row_base = (qs + 1) & ~(int64_t)3;          // rows above the chunk's first query (4-aligned: fp8 row scales)
+    if ((rc = dequant_rows_to(idx, qs, nq, qbuf, st)) != SVS_OK) return rc;
+    FuseLaunch fl{c->hist, c->cand, thr, 0, TgPairs{(long long)qs, (long long)row_base, (long long)q0, 1}};
+    if ((rc = launch_scores_any(idx, c, qbuf, n - row_base, nq, nullptr, 0, fl, st)) != SVS_OK) return rc;
+    hipLaunchKernelGGL(collect_pairs_kernel, dim3(nq), dim3(256), 0, st, c->hist, (const uint64_t*)c->cand, (long long)qs, (long long)q0,
+                       (const uint32_t*)(idx->dead_list.empty() ? nullptr : idx->dead_bits_dev), gstate, LIST_CAP, l_key, l_i, l_j);
+  }
+  HIP_TRY(hipGetLastError());
+  uint32_t hs[4] = {0, 0, 0, 0};
+  HIP_TRY(hipMemcpyAsync(hs, gstate, 16, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (hs[1] || hs[0] > LIST_CAP)
+    return fail(SVS_ERR_UNSUPPORTED, "top_pairs: more than %u pairs (or 32,768 for one row) score at least the %d-th best of the first %lld rows: "
+                                      "near-duplicate documents en masse", LIST_CAP, count, (long long)P);
+  const uint32_t L = hs[0];
+  if ((int64_t)L < count) return fail(SVS_ERR_DEVICE, "internal: pair list holds %u < %d entries", L, count);
+  std::vector<uint32_t> hk(L), hi(L), hj(L);
+  HIP_TRY(hipMemcpy(hk.data(), l_key, (size_t)L * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(hi.data(), l_i, (size_t)L * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(hj.data(), l_j, (size_t)L * 4, hipMemcpyDeviceToHost));
+  std::vector<uint32_t> order(L);
+  for (uint32_t t = 0; t < L; ++t) order[t] = t;
+  auto before = [&](uint32_t a, uint32_t b) {   // (score desc, i desc, j desc)
+    if (hk[a] != hk[b]) return hk[a] > hk[b];
+    if (hi[a] != hi[b]) return hi[a] > hi[b];
+    return hj[a] > hj[b];
+  };
+  std::partial_sort(order.begin(), order.begin() + count, order.end(), before);
+  for (int t = 0; t < count; ++t) {
+    out_scores[t] = key_score(hk[order[t]]);
+    out_i[t] = (int64_t)hi[order[t]] + idx->row_offset;
+    out_j[t] = (int64_t)hj[order[t]] + idx->row_offset;
+  }
+  return SVS_OK;
+}
 
 int check_query_args(const svs_index* idx, const void* q, int nq, int d) {
   if (!idx) return fail(SVS_ERR_INVALID, "null index");
@@ -1448,62 +1612,17 @@ int32_t svs_index_top_pairs(svs_index* idx, int32_t k, float* out_scores, int64_
   if (out_count) *out_count = count;
   if (count == 0) return SVS_OK;
   if (!out_scores || !out_i || !out_j) return fail(SVS_ERR_INVALID, "null output");
-  if (n * np > 0xffffffffll) return fail(SVS_ERR_UNSUPPORTED, "pairwise scores need n*n <= 2^32 (n = %lld)", (long long)n);
   HIP_TRY(hipSetDevice(idx->device));
   Ctx* c = nullptr;
   int rc;
   if ((rc = ctx_acquire(idx, nullptr, true, &c)) != SVS_OK) return rc;
   struct CtxGuard { svs_index* i; Ctx* c; ~CtxGuard() { ctx_release(i, c); } } cg{idx, c};
-  hipStream_t st = c->stream;
-  // every row is a query: read the corpus back as f32 queries (what the index holds)
-  float* qall = nullptr;
-  float* S = nullptr;
-  float* d_s = nullptr;
-  int64_t* d_r = nullptr;
-  struct Tmp { float** a; float** b; float** cc; int64_t** d; ~Tmp() { (void)hipFree(*a); (void)hipFree(*b); (void)hipFree(*cc); (void)hipFree(*d); } } tmp{&qall, &S, &d_s, &d_r};
-  HIP_TRY(hipMalloc((void**)&qall, (size_t)n * idx->d * sizeof(float)));
-  HIP_TRY(hipMalloc((void**)&S, (size_t)n * np * sizeof(float)));
-  HIP_TRY(hipMalloc((void**)&d_s, (size_t)count * sizeof(float)));
-  HIP_TRY(hipMalloc((void**)&d_r, (size_t)count * sizeof(int64_t)));
-  if (idx->dtype == SVS_DTYPE_F32)
-    HIP_TRY(hipMemcpy2DAsync(qall, (size_t)idx->d * sizeof(float), idx->rows, (size_t)idx->ld * sizeof(float),
-                             (size_t)idx->d * sizeof(float), (size_t)n, hipMemcpyDeviceToDevice, st));
-  else if (idx->dtype == SVS_DTYPE_F16)
-    hipLaunchKernelGGL(dequant_rows_f16_kernel, dim3(2048), dim3(256), 0, st, (const _Float16*)idx->rows, (int64_t)0, n, idx->d, idx->ld, qall);
-  else
-    hipLaunchKernelGGL(dequant_rows_fp8_kernel, dim3(2048), dim3(256), 0, st, (const uint8_t*)idx->rows, idx->row_scales, (int64_t)0, n,
-                       idx->d, idx->ld, qall);
-  // S = M * M^T in blocks of query rows (the reference's np.dot(M, M.T), src/svs/kb.py:1651)
-  const int chunk = 1024;
-  for (int64_t q0 = 0; q0 < n; q0 += chunk) {
-    const int nq = (int)std::min<int64_t>(chunk, n - q0);
-    if ((rc = launch_scores_any(idx, c, qall + q0 * idx->d, idx->n, nq, S + q0 * np, np, FuseLaunch{}, st)) != SVS_OK) return rc;
-  }
-  hipLaunchKernelGGL(mask_upper_triangle_kernel, dim3(4096), dim3(256), 0, st, S, n, np);
-  if (!idx->dead_list.empty())
-    hipLaunchKernelGGL(mask_dead_pairs_kernel, dim3(1024), dim3(256), 0, st, S, n, np, idx->dead_dev, (int64_t)idx->dead_list.size());
-  // top-k of the flattened upper triangle; the flat index i*np + j orders ties like the reference
-  const int64_t flat = n * np;
-  const bool path_a = flat > SORT_CAP && count <= SEL_KMAX;
-  if (path_a && c->hist_cap < 1) {
-    HIP_TRY(hipMalloc((void**)&c->hist, (size_t)SCR_WORDS * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void**)&c->cand, (size_t)CAND_CAP * sizeof(uint64_t)));
-    HIP_TRY(hipMemsetAsync(c->hist, 0, (size_t)SCR_WORDS * sizeof(uint32_t), st));
-    c->hist_cap = 1;
-  }
-  const int64_t save_off = idx->row_offset;
-  (void)save_off;
-  if ((rc = run_select(idx, c, S, flat, flat, 1, count, count, d_s, d_r, st, /*row_offset=*/0)) != SVS_OK) return rc;
-  HIP_TRY(hipGetLastError());
-  std::vector<int64_t> flat_rows((size_t)count);
-  HIP_TRY(hipMemcpyAsync(out_scores, d_s, (size_t)count * sizeof(float), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(flat_rows.data(), d_r, (size_t)count * sizeof(int64_t), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  for (int t = 0; t < count; ++t) {
-    out_i[t] = flat_rows[t] / np + idx->row_offset;
-    out_j[t] = flat_rows[t] % np + idx->row_offset;
-  }
-  return SVS_OK;
+  // Small corpora: materialise n x n like the reference (src/svs/kb.py:1651).  Past n^2 = 2^32 scores
+  // (or with variant 1, for A/B and tests): tiled GEMM with the i < j mask and a threshold in the
+  // fused epilogue, nothing materialised but a prefix block.
+  if (n * np <= 0xffffffffll && idx->variant.load() != 1)
+    return top_pairs_materialised(idx, c, n, count, out_scores, out_i, out_j);
+  return top_pairs_tiled(idx, c, count, out_scores, out_i, out_j);
 }
 
 int32_t svs_index_debug_dequant(svs_index* idx, int64_t row0, int64_t nrows, float* out) {

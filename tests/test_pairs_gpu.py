@@ -74,3 +74,72 @@ def test_top_pairs_ties_and_edges(gpu):
     one = DeviceIndex(np.ones((1, 4), dtype=np.float32))
     assert one.top_pairs(5) == []
     one.release()
+
+
+# ---- corpora past n^2 = 2^32 scores: tiled pair-mode GEMM (svs_amd.hip top_pairs_tiled) ----------
+@pytest.mark.parametrize("n,d,k,dtype", [(5000, 256, 300, "f32"), (20000, 512, 1000, "f16"), (20000, 256, 200, "fp8"),
+                                         (3001, 128, 5000, "f16"), (9000, 1536, 100, "f16"), (1100, 64, 50, "f32")])
+def test_tiled_pairs_equal_materialised(gpu, n, d, k, dtype):
+    """variant 1 forces the large-corpus path on a corpus the materialised path can also do: the
+    two must return the same pairs in the same order with the same scores (same MFMA kernels, the
+    same (score, i, j) order key)."""
+    from svs_amd import DeviceIndex
+    m, _ = corpus_and_query("gaussian", 900 + n, n, d, 1)
+    m[n // 2] = m[7]                 # exact duplicates: ties at the top of the list
+    m[n - 1] = m[7]
+    m[n - 2] = m[n // 3]
+    idx = DeviceIndex(m, dtype=dtype)
+    ref = idx.top_pairs(k)
+    idx.set_variant(1)
+    got = idx.top_pairs(k)
+    assert got == ref
+    # tombstones: the duplicates' rows disappear from both
+    idx.set_variant(0)
+    idx.mask_rows([7, n - 2])
+    ref = idx.top_pairs(k)
+    idx.set_variant(1)
+    got = idx.top_pairs(k)
+    assert got == ref and all(i not in (7, n - 2) and j not in (7, n - 2) for _, i, j in got)
+    idx.release()
+
+
+def _cpu_top_pairs_chunked(md, k, chunk=2000):
+    """Top-k pairs of md.md^T without the n x n matrix: per chunk of query rows keep the pairs
+    that can still make the list, then the reference's order (score desc, flat index desc)."""
+    n = md.shape[0]
+    best = []   # (score, i, j)
+    for r0 in range(0, n, chunk):
+        s = np.dot(md[r0:r0 + chunk], md.T)
+        ii = np.arange(r0, min(n, r0 + chunk))[:, None]
+        s[np.arange(n)[None, :] <= ii] = -np.inf
+        flat = s.ravel()
+        kk = min(k, flat.size)
+        part = np.argpartition(-flat, kk - 1)[:kk]
+        best += [(float(flat[p]), int(r0 + p // n), int(p % n)) for p in part if np.isfinite(flat[p])]
+        best.sort(key=lambda t: (-t[0], -t[1], -t[2]))
+        best = best[:k]
+    return best
+
+
+@pytest.mark.parametrize("n,d,k,dtype", [(120_000, 128, 200, "f32"), (150_000, 256, 500, "f16")])
+def test_top_pairs_large_corpus(gpu, n, d, k, dtype):
+    """n >= 100k (n^2 > 2^32: nothing the size of the score matrix exists anywhere).  Planted
+    near-duplicates must come out on top; the whole list against a chunked numpy restatement of
+    get_top_pairs (reference src/svs/util.py:206-233) on the stored rows."""
+    from svs_amd import DeviceIndex
+    m, _ = corpus_and_query("gaussian", 31 + n, n, d, 1)
+    rng = np.random.default_rng(5)
+    planted = []
+    for t in range(40):
+        a, b = sorted(int(x) for x in rng.choice(n, 2, replace=False))
+        m[b] = m[a] + np.float32(0.02 * (t + 1) / 40) * rng.standard_normal(d).astype(np.float32) * np.abs(m[a]).mean()
+        planted.append((a, b))
+    idx = DeviceIndex(m, dtype=dtype)
+    md = idx.stored_rows()
+    got = idx.top_pairs(k)
+    exp = _cpu_top_pairs_chunked(md, k)
+    assert len(got) == k
+    _check(got, exp, tol=2e-5 * max(1.0, float(np.abs(exp[0][0]))))
+    top = {(i, j) for _, i, j in got[:45]}     # random pairs of unit rows stay below ~0.5; planted ones are ~1
+    assert len(top & set(planted)) >= 35
+    idx.release()
