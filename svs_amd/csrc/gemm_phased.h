@@ -51,9 +51,23 @@ constexpr int PG_SLOT = 1024;             // u32x4 per slot (16 KiB)
 constexpr int PG_LDS_BYTES = 8 * PG_SLOT * 16;
 constexpr int PG_THREADS = 512;
 
-#ifndef PG_VMCNT
-#define PG_VMCNT 10
+// PG_DMA_IN_MMA: a phase's two LDS-DMA pieces are issued between its MFMAs (after MFMA pair
+// PG_DMA_AT0 of the first k half and PG_DMA_AT1 of the second) instead of with its fragment reads.
+// The stream then runs half a phase later: at a phase's counted wait the youngest half-tile in
+// flight is P + 6, and "everything up to P + 2" is all but the FOUR youngest half-tiles: vmcnt(8).
+#ifndef PG_DMA_IN_MMA
+#define PG_DMA_IN_MMA 1
 #endif
+#ifndef PG_DMA_STAGGER
+#define PG_DMA_STAGGER 0
+#endif
+#ifndef PG_DMA_AT0
+#define PG_DMA_AT0 1
+#endif
+#ifndef PG_DMA_AT1
+#define PG_DMA_AT1 1
+#endif
+#define PG_VMCNT (kDmaInMma ? 8 : 10)
 
 #ifdef PG_CLOCKS   // tools/gemm_phased_bench.hip only: shader cycles and 100 MHz ticks a workgroup spent in the kernel
 __device__ unsigned long long* pg_clock_buf;
@@ -104,6 +118,37 @@ __device__ __forceinline__ void pg_tile_of(int id, int gx, int gy, int* bx, int*
     *bx = full + t % rem;
     *by = t / rem;
   }
+}
+
+// a buffer descriptor whose words are explicitly wave-uniform (scalar registers)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pg_rsrc(const void* p, int bytes) {
+  const uint64_t a = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
+template <int N, class F>
+__device__ __forceinline__ void pg_static_for(F&& f) {   // f(integral_constant<0>) ... f(integral_constant<N - 1>)
+  if constexpr (N > 0) {
+    pg_static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
+// Fused epilogue, second sweep: the lanes whose score is not below the threshold (a NaN passes) store
+// (score bits, base + IMM) at their LDS address `ak` and step it; every lane leaves with exec all ones.
+template <int IMM>
+__device__ __forceinline__ void pg_park_if(unsigned& ak, float v, float thr, uint32_t base) {
+  uint32_t code;
+  asm volatile(
+      "v_add_u32_e32 %1, %5, %4\n\t"
+      "v_cmpx_nlt_f32_e32 vcc, %2, %3\n\t"
+      "ds_write2_b32 %0, %2, %1 offset1:1\n\t"
+      "v_add_u32_e32 %0, 8, %0\n\t"
+      "s_mov_b64 exec, -1"
+      : "+v"(ak), "=&v"(code)
+      : "v"(v), "v"(thr), "v"(base), "n"(IMM)
+      : "vcc", "memory");
 }
 
 struct PgTile {
@@ -167,9 +212,9 @@ constexpr int PG_SIDE_THR = PG_SIDE;                    // f32 [2][256]
 constexpr int PG_SIDE_RS = PG_SIDE_THR + 2048;          // f32 [2][256] row scales (fp8)
 constexpr int PG_SIDE_QS = PG_SIDE_RS + 2048;           // f32 [2][256] query scales (fp8)
 constexpr int PG_SIDE_CNT = PG_SIDE_QS + 2048;          // u32 [2][8]: candidates parked by each wave
-constexpr int PG_SIDE_KEY = PG_SIDE_CNT + 64;           // u64 [2][PG_PARK]: wave w owns entries [w * PG_PARK / 8, ..)
-constexpr int PG_SIDE_QID = PG_SIDE_KEY + 2 * PG_PARK * 8;   // u32 [2][PG_PARK]
-constexpr int PG_LDS_TOTAL = PG_SIDE_QID + 2 * PG_PARK * 4;  // 161,808 bytes of the 163,840
+constexpr int PG_SIDE_KEY = PG_SIDE_CNT + 64;           // u32 [2][PG_PARK][2]: (score bits, code); wave w owns entries [w * PG_PARK / 8, ..)
+constexpr int PG_LDS_TOTAL = PG_SIDE_KEY + 2 * PG_PARK * 8;  // 153,664 bytes of the 163,840
+// a parked candidate's code: row inside the tile (8 bits) | query inside the tile << 8
 constexpr int PG_FLUSH_KT = 2, PG_MIN_KT = 6;   // the flush brackets k-tiles 2 and 3 of the next tile
 
 // LDS accesses of the epilogue / flush: inline asm, so that hipcc neither orders them against the
@@ -216,7 +261,9 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
   const int r16 = lane & 15, g = lane >> 4;
   const int KT = ldb / TG_BKB;                       // k-tiles per output tile (even, >= PG_MIN_KT: checked by the host)
   const int G = gridDim.x, total = gx * gy;
-  const int my_tiles = (total - (int)blockIdx.x + G - 1) / G;
+  // (integer division runs on the vector ALU; whatever hangs on its result -- the loop bounds, the tile
+  //  descriptors -- must be told that it is wave-uniform, or it is kept in VGPRs: see tile_desc)
+  const int my_tiles = __builtin_amdgcn_readfirstlane((total - (int)blockIdx.x + G - 1) / G);
 
   // ---- per-lane constants of the staging side: byte offset of the lane's 16 bytes inside a tile
   int voffA[2][2], voffB[2][2];                      // [half][instruction]
@@ -249,16 +296,21 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
     if (j < my_tiles) {
       int bx, by;
       pg_tile_of((int)blockIdx.x + j * G, gx, gy, &bx, &by);
+      // (the divisions above run on the vector ALU: without these two, hipcc keeps the descriptors
+      //  below in VGPRs and wraps EVERY LDS-DMA instruction in a waterfall loop -- four
+      //  v_readfirstlane, two compares, a saveexec and a branch per piece, in among the MFMAs)
+      bx = __builtin_amdgcn_readfirstlane(bx);
+      by = __builtin_amdgcn_readfirstlane(by);
       t.row0 = (int64_t)bx * PG_TILE;
       t.q0 = by * PG_TILE;
       const int64_t live = n - t.row0 < PG_TILE ? n - t.row0 : PG_TILE;
-      t.a = __builtin_amdgcn_make_buffer_rsrc((void*)(M + t.row0 * ldb), 0, (int)(live * ldb), 0x00020000);
-      t.b = __builtin_amdgcn_make_buffer_rsrc((void*)(Q + (int64_t)t.q0 * ldb), 0, PG_TILE * ldb, 0x00020000);
+      t.a = pg_rsrc(M + t.row0 * ldb, (int)(live * ldb));
+      t.b = pg_rsrc(Q + (int64_t)t.q0 * ldb, PG_TILE * ldb);
     } else {   // no such tile: zero records, every load through it is dropped
       t.row0 = 0;
       t.q0 = 0;
-      t.a = __builtin_amdgcn_make_buffer_rsrc((void*)M, 0, 0, 0x00020000);
-      t.b = __builtin_amdgcn_make_buffer_rsrc((void*)Q, 0, 0, 0x00020000);
+      t.a = pg_rsrc(M, 0);
+      t.b = pg_rsrc(Q, 0);
     }
     return t;
   };
@@ -266,21 +318,22 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
 
   // kind: 0 = B0, 1 = A0, 2 = B1, 3 = A1.  NEXT: the half-tile belongs to the next output tile
   // (a compile-time fact: only the last two k-tiles of a tile stage across the seam).
-  auto stage = [&](auto KIND, auto SLOT, auto NEXT, int kt) {
-    constexpr int kind = decltype(KIND)::value, slot = decltype(SLOT)::value;
+  auto stage_piece = [&](auto KIND, auto SLOT, auto NEXT, int kt, auto JJ) {
+    constexpr int kind = decltype(KIND)::value, slot = decltype(SLOT)::value, jj = decltype(JJ)::value;
     constexpr bool next = decltype(NEXT)::value != 0;
-    const int soff = EXP == 21 ? 0 : kt * TG_BKB;   // (ablation 21: always the first k-tile: L2 hits)
+    const int soff = (EXP == 21 || EXP == 25) ? 0 : kt * TG_BKB;   // (ablation 21: always the first k-tile: L2 hits)
     const __amdgpu_buffer_rsrc_t rs = (kind & 1) ? (next ? nxt.a : cur.a) : (next ? nxt.b : cur.b);
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-      const int vo = (kind & 1) ? voffA[kind >> 1][jj] : voffB[kind >> 1][jj];
-      if constexpr (EXP == 20 && (kind & 1))   // (ablation: corpus rows nontemporal)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(pg_lds + slot * PG_SLOT + (wave + 8 * jj) * 64),
-                                                 16, vo, soff, 0, 2);
-      else
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(pg_lds + slot * PG_SLOT + (wave + 8 * jj) * 64),
-                                                 16, vo, soff, 0, 0);
-    }
+    const int vo = (kind & 1) ? voffA[kind >> 1][jj] : voffB[kind >> 1][jj];
+    if constexpr (EXP == 20 && (kind & 1))   // (ablation: corpus rows nontemporal)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(pg_lds + slot * PG_SLOT + (wave + 8 * jj) * 64),
+                                               16, vo, soff, 0, 2);
+    else
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(pg_lds + slot * PG_SLOT + (wave + 8 * jj) * 64),
+                                               16, vo, soff, 0, 0);
+  };
+  auto stage = [&](auto KIND, auto SLOT, auto NEXT, int kt) {
+    stage_piece(KIND, SLOT, NEXT, kt, std::integral_constant<int, 0>{});
+    stage_piece(KIND, SLOT, NEXT, kt, std::integral_constant<int, 1>{});
   };
   // side data of tile `t` into copy `par`: every wave issues the same instructions (waves 4-7
   // repeat waves 0-3: same bytes to the same place), 256 bytes each
@@ -305,7 +358,7 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
 
   f32x4_t acc[MT][NT];
   u32x4 fa[4][2], fb0[2][2], fb1[2][2];
-  if constexpr (EXP == 2) {   // (ablation without fragment reads: defined operands)
+  if constexpr (EXP == 2 || EXP == 5 || EXP == 25 || EXP == 26) {   // (ablation without fragment reads: defined operands)
     const u32x4 c = {0x3c003c00u + (uint32_t)lane, 0x3c003c00u, 0x38003800u, 0x3c003c00u};
 #pragma unroll
     for (int i = 0; i < 4; ++i) fa[i][0] = fa[i][1] = c;
@@ -313,17 +366,34 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
     for (int i = 0; i < 2; ++i) fb0[i][0] = fb0[i][1] = fb1[i][0] = fb1[i][1] = c;
   }
   // one quadrant: rows 64 i .. 64 i + 63, queries 32 j .. 32 j + 31 of the wave tile
-  auto mma = [&](auto I, auto J, const u32x4 (&fb)[2][2]) {
+  // s0 / s1: the phase's two LDS-DMA pieces, issued BETWEEN the MFMAs (PG_DMA_IN_MMA): beside bare
+  // MFMAs a piece costs the wave ~60 cycles of issue, inside the reading segment (12 ds_read_b128
+  // of four waves in flight) 100-185 (MI355X_MICROARCH.md, timing table) -- and the reading
+  // segment, not the MFMAs, was what set the barrier interval (~460 cycles for 256 of MFMA)
+  auto mma = [&](auto I, auto J, const u32x4 (&fb)[2][2], auto&& s0, auto&& s1) {
     constexpr int i = decltype(I)::value, j = decltype(J)::value;
     if constexpr (EB == 2) {
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt)
             acc[i * 4 + mt][j * 2 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
                 __builtin_bit_cast(h8, fa[mt][h]), __builtin_bit_cast(h8, fb[nt][h]), acc[i * 4 + mt][j * 2 + nt], 0, 0, 0);
+#if PG_DMA_STAGGER
+          // the four waves of a group share the CU's vector-memory front end (64 B/clk: 16 cycles per
+          // piece): wave wc issues after MFMA pair wc, so no piece queues behind another wave's
+          if (wc == mt) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (h == 0) s0(); else s1();
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#else
+          if (h == 0 && mt == PG_DMA_AT0) { __builtin_amdgcn_sched_barrier(0); s0(); __builtin_amdgcn_sched_barrier(0); }
+          if (h == 1 && mt == PG_DMA_AT1) { __builtin_amdgcn_sched_barrier(0); s1(); __builtin_amdgcn_sched_barrier(0); }
+#endif
+        }
     } else {
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
@@ -336,16 +406,20 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
           acc[i * 4 + mt][j * 2 + nt] =
               __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(x, y, acc[i * 4 + mt][j * 2 + nt], 0, 0, 0, 0, 0, 0);
         }
+        if (mt == 0) { __builtin_amdgcn_sched_barrier(0); s0(); __builtin_amdgcn_sched_barrier(0); }
+        if (mt == 2) { __builtin_amdgcn_sched_barrier(0); s1(); __builtin_amdgcn_sched_barrier(0); }
       }
     }
   };
 #define PG_C(v) std::integral_constant<int, (v)>{}
-  constexpr bool kStage = EXP != 1, kRead = EXP != 2, kMma = EXP != 3;
+  constexpr bool kStage = EXP != 1 && EXP != 26, kRead = EXP != 2 && EXP != 5 && EXP != 25 && EXP != 26, kMma = EXP != 3 && EXP != 5 && EXP != 25 && EXP != 26;   // (26: barriers only)   // (EXP 5: LDS-DMA and barriers only)
+  constexpr bool kDmaInMma = PG_DMA_IN_MMA && EXP != 30;   // (EXP 30: pieces issued with the fragment reads, A/B)
   // what follows the loads of a phase: [retire the B reads] wait for the NEXT phase's data, barrier,
   // fragments in, 16 MFMAs at raised priority (keeps hipcc from moving them over the barriers), barrier
-#define PG_SYNC_AND_MMA(PH, I, J, FB, LGKM8, LAND)                          \
+#define PG_SYNC_AND_MMA(PH, I, J, FB, LGKM8, LAND, KIND, SLOT, NEXT, KT_)    \
   do {                                                                      \
-    if (LGKM8 && kRead) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");  \
+    if constexpr (kStage && !kDmaInMma) stage(PG_C(KIND), PG_C(SLOT), PG_C(NEXT), KT_); \
+    if (LGKM8 && kRead && !kDmaInMma) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");  \
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PG_VMCNT) : "memory");         \
     PG_STAMP(PH, 0);                                                        \
     __builtin_amdgcn_s_barrier();                                           \
@@ -353,7 +427,11 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
     PG_STAMP(PH, 1);                                                        \
     __builtin_amdgcn_sched_barrier(0);                                      \
     __builtin_amdgcn_s_setprio(1);                                          \
-    if constexpr (kMma) mma(PG_C(I), PG_C(J), FB);                          \
+    if constexpr (kMma)                                                     \
+      mma(PG_C(I), PG_C(J), FB,                                             \
+          [&]() { if constexpr (kStage && kDmaInMma) stage_piece(PG_C(KIND), PG_C(SLOT), PG_C(NEXT), KT_, PG_C(0)); }, \
+          [&]() { if constexpr (kStage && kDmaInMma) stage_piece(PG_C(KIND), PG_C(SLOT), PG_C(NEXT), KT_, PG_C(1)); }); \
+    else if constexpr (kStage && kDmaInMma) stage(PG_C(KIND), PG_C(SLOT), PG_C(NEXT), KT_); \
     __builtin_amdgcn_s_setprio(0);                                          \
     __builtin_amdgcn_sched_barrier(0);                                      \
     PG_STAMP(PH, 2);                                                        \
@@ -380,19 +458,15 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
       __builtin_amdgcn_sched_barrier(0);
       pg_read_a<mine + 1>(fa, adrA);
     }
-    if constexpr (kStage) stage(PG_C(3), PG_C(other + 3), PG_C(n1), k1);
-    PG_SYNC_AND_MMA(0, 0, 0, fb0, true, (pg_landed_b(fb0), pg_landed_a(fa)));
+    PG_SYNC_AND_MMA(0, 0, 0, fb0, true, (pg_landed_b(fb0), pg_landed_a(fa)), 3, other + 3, n1, k1);
     // phase 1: B1 in; quadrant (0, 1); stage B0 of the k-tile after next (over this one's B0)
     if constexpr (kRead) pg_read_b<mine + 2>(fb1, adrB);
-    if constexpr (kStage) stage(PG_C(0), PG_C(mine + 0), PG_C(n2), k2);
-    PG_SYNC_AND_MMA(1, 0, 1, fb1, false, pg_landed_b(fb1));
+    PG_SYNC_AND_MMA(1, 0, 1, fb1, false, pg_landed_b(fb1), 0, mine + 0, n2, k2);
     // phase 2: A1 in; quadrant (1, 1); stage A0
     if constexpr (kRead) pg_read_a<mine + 3>(fa, adrA);
-    if constexpr (kStage) stage(PG_C(1), PG_C(mine + 1), PG_C(n2), k2);
-    PG_SYNC_AND_MMA(2, 1, 1, fb1, false, pg_landed_a(fa));
+    PG_SYNC_AND_MMA(2, 1, 1, fb1, false, pg_landed_a(fa), 1, mine + 1, n2, k2);
     // phase 3: nothing to read; quadrant (1, 0); stage B1
-    if constexpr (kStage) stage(PG_C(2), PG_C(mine + 2), PG_C(n2), k2);
-    PG_SYNC_AND_MMA(3, 1, 0, fb0, false, (void)0);
+    PG_SYNC_AND_MMA(3, 1, 0, fb0, false, (void)0, 2, mine + 2, n2, k2);
   };
 
   // ---- flush of the candidates parked by the PREVIOUS tile (copy pp, queries pq0 ..): step A
@@ -400,14 +474,15 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
   // k-tiles = 32 counted vmcnt waits later -- stores the keys
   uint32_t fslot[2] = {0u, 0u};
   int f_pp = 0, f_q0 = 0;     // wave-uniform
+  int64_t f_row0 = 0;
   auto flush_a = [&]() {
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < PG_PARK / PG_THREADS; ++r) {
       const int e = (int)threadIdx.x + r * PG_THREADS, w = e / (PG_PARK / 8), i = e % (PG_PARK / 8);
       const uint32_t nw = pg_lds_read_u32(PG_SIDE_CNT + (f_pp * 8 + w) * 4);
       if ((uint32_t)i < nw) {
-        const uint32_t q = pg_lds_read_u32(PG_SIDE_QID + (f_pp * PG_PARK + e) * 4);
-        uint32_t* p = fstate_words + (int64_t)(f_q0 + (int)q) * fstate_stride;
+        const uint32_t code = pg_lds_read_u32(PG_SIDE_KEY + (f_pp * PG_PARK + e) * 8 + 4);
+        uint32_t* p = fstate_words + (int64_t)(f_q0 + (int)(code >> 8)) * fstate_stride;
         const uint32_t one = 1u;
         asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(fslot[r]) : "v"(p), "v"(one) : "memory");
       }
@@ -417,14 +492,14 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
     if (!waited) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(fslot[0]), "+v"(fslot[1]) : "n"(PG_VMCNT) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" : "+v"(fslot[0]), "+v"(fslot[1])::"memory");
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < PG_PARK / PG_THREADS; ++r) {
       const int e = (int)threadIdx.x + r * PG_THREADS, w = e / (PG_PARK / 8), i = e % (PG_PARK / 8);
       const uint32_t nw = pg_lds_read_u32(PG_SIDE_CNT + (f_pp * 8 + w) * 4);
       if ((uint32_t)i < nw && fslot[r] < fcap) {
-        const uint32_t q = pg_lds_read_u32(PG_SIDE_QID + (f_pp * PG_PARK + e) * 4);
-        const uint64_t sr = pg_lds_read_u64(PG_SIDE_KEY + (f_pp * PG_PARK + e) * 8);   // (score bits, row)
-        fcand[(int64_t)(f_q0 + (int)q) * fcap + fslot[r]] =
-            ((uint64_t)score_key(__builtin_bit_cast(float, (uint32_t)(sr >> 32))) << 32) | (uint32_t)sr;
+        const uint64_t sc = pg_lds_read_u64(PG_SIDE_KEY + (f_pp * PG_PARK + e) * 8);   // (score bits, code)
+        const uint32_t code = (uint32_t)(sc >> 32);
+        fcand[(int64_t)(f_q0 + (int)(code >> 8)) * fcap + fslot[r]] =
+            ((uint64_t)score_key(__builtin_bit_cast(float, (uint32_t)sc)) << 32) | (uint32_t)(f_row0 + (code & 255u));
       }
     }
   };
@@ -449,8 +524,7 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
       const int lr0 = wrow + 4 * g;                                        // the lane's first row inside the tile
       const int lim = (int)(n - t.row0 < PG_TILE ? n - t.row0 : PG_TILE);  // live rows of this tile
       constexpr int WCAP = PG_PARK / 8;
-      const unsigned kadr = PG_SIDE_KEY + (par * PG_PARK + wave * WCAP) * 8, qadr = PG_SIDE_QID + (par * PG_PARK + wave * WCAP) * 4;
-      const uint32_t row_lo = (uint32_t)(t.row0 + lr0);
+      const unsigned kadr = PG_SIDE_KEY + (par * PG_PARK + wave * WCAP) * 8;
       int wcount = 0;   // wave-uniform
       auto pass = [&](auto FULL, auto QALL) {
         constexpr bool full = decltype(FULL)::value, qall = decltype(QALL)::value;   // whole tile inside the corpus / the batch
@@ -459,6 +533,10 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
           const int ql = wq + j * 16 + r16;
           const float thr = pg_lds_read_f32(PG_SIDE_THR + par * 1024 + ql * 4);
           const unsigned long long qokm = __ballot(t.q0 + ql < nq);
+          // (opaque: the 128 codes of a lane do not depend on the tile, and hipcc otherwise computes them all at
+          //  kernel entry and spills them -- ~500 registers' worth of scratch traffic behind vmcnt(0) waits)
+          uint32_t cbase = (uint32_t)(lr0 | (ql << 8));
+          asm volatile("" : "+v"(cbase));
           float qs = 1.f;
           if constexpr (EB == 1) qs = pg_lds_read_f32(PG_SIDE_QS + par * 1024 + ql * 4);
 #pragma unroll
@@ -483,9 +561,8 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
                 const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask[r] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask[r], 0u));
                 if (hit) {
                   const int slot = wcount + rank;
-                  if (slot < WCAP) {   // (score bits, row): the order-preserving key is made at flush time
-                    pg_lds_write_u64(kadr + slot * 8, ((uint64_t)__builtin_bit_cast(uint32_t, v[r]) << 32) | (row_lo + (uint32_t)(i * 16 + r)));
-                    pg_lds_write_u32(qadr + slot * 4, (uint32_t)ql);
+                  if (slot < WCAP) {   // (score bits, code): the order-preserving key is made at flush time
+                    pg_lds_write_u64(kadr + slot * 8, ((uint64_t)(cbase + (uint32_t)(i * 16 + r)) << 32) | __builtin_bit_cast(uint32_t, v[r]));
                   } else {
                     __hip_atomic_fetch_or(fstate_words + (int64_t)(t.q0 + ql) * fstate_stride, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                   }
@@ -496,9 +573,73 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
           }
         }
       };
-      // (interior tiles -- all but the last row tile and the last query tile -- test one compare per register)
-      if (lim == PG_TILE && t.q0 + PG_TILE <= nq) pass(std::true_type{}, std::true_type{});
-      else pass(std::false_type{}, std::false_type{});
+      // Interior tiles (all but the last row tile and the last query tile): the same result WITHOUT a
+      // branch per register.  With thresholds from an n / 64 prefix ~420 candidates survive per tile:
+      // a third of the registers held one, and the compare -> mask -> branch -> rank path above cost
+      // 21 k cycles per tile (3.9 k with no survivor).  Here: (1) every lane counts its own survivors
+      // (compare + add-with-carry per register), (2) one wave scan gives each lane the first of ITS
+      // slots in the wave's eighth, (3) a second sweep parks them: v_cmpx makes the survivors the
+      // active lanes, they store (score, code) and step their address, exec is restored -- five
+      // instructions per register, the same whatever survives.
+      auto sweep = [&]() {
+        float thr[NT];
+        uint32_t base[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int ql = wq + j * 16 + r16;
+          thr[j] = pg_lds_read_f32(PG_SIDE_THR + par * 1024 + ql * 4);
+          base[j] = (uint32_t)(lr0 | (ql << 8));
+        }
+        auto val = [&](int i, int j, int r) {
+          float v = acc[i][j][r];
+          if constexpr (EB == 1)
+            v *= pg_lds_read_f32(PG_SIDE_QS + par * 1024 + (wq + j * 16 + r16) * 4) * pg_lds_read_f32(PG_SIDE_RS + par * 1024 + (lr0 + i * 16 + r) * 4);
+          return v;
+        };
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cnt += !(val(i, j, r) < thr[j]) ? 1u : 0u;   // (a NaN passes)
+        // inclusive scan over the wave: four row shifts, then the two row broadcasts
+        uint32_t x = cnt;
+        x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);
+        x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);
+        x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);
+        x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);
+        x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
+        x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
+        const int total = __builtin_amdgcn_readlane((int)x, 63);
+        if (__builtin_expect(total > WCAP, 0)) {
+          // more than the wave's eighth holds: give the fused path up for the queries concerned
+          // (every query this lane has a survivor for, conservatively all four of its columns)
+          if (cnt != 0) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              __hip_atomic_fetch_or(fstate_words + (int64_t)(t.q0 + wq + j * 16 + r16) * fstate_stride, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          wcount = 0;
+        } else {
+          wcount = total;
+          if (total != 0) {
+            unsigned ak = kadr + (x - cnt) * 8;   // the lane's first slot
+            // (the code is computed INSIDE the asm, from a literal: handed in as an operand, hipcc computes all 128
+            //  codes ahead, spills them, and reloads each behind a vmcnt(0) that drains the LDS-DMA ring)
+            pg_static_for<NT>([&](auto J) {
+              pg_static_for<MT>([&](auto I) {
+                pg_static_for<4>([&](auto R) {
+                  constexpr int j = decltype(J)::value, i = decltype(I)::value, r = decltype(R)::value;
+                  pg_park_if<i * 16 + r>(ak, val(i, j, r), thr[j], base[j]);
+                });
+              });
+            });
+          }
+        }
+      };
+      if (lim == PG_TILE && t.q0 + PG_TILE <= nq && EXP != 31) sweep();
+      else pass(std::false_type{}, std::false_type{});   // (EXP 31: the branchy path everywhere, A/B)
       if (lane == 0) pg_lds_write_u32(PG_SIDE_CNT + (par * 8 + wave) * 4, (uint32_t)(wcount < WCAP ? wcount : WCAP));
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // parked entries written before this wave's next barrier
     }
@@ -566,6 +707,7 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
     }
     f_pp = tp;
     f_q0 = cur.q0;
+    f_row0 = cur.row0;
     cur = nxt;
     nxt = tile_desc(T + 2);
   }

@@ -610,18 +610,18 @@ int launch_tiled_bn(const svs_index* idx, Ctx* c, int64_t n_rows, int nq, float*
 }
 
 // 256 x 256 output tiles, persistent workgroups, four-phase k-tiles (gemm_phased.h)
-template <bool FUSE, int EB>
+template <bool FUSE, int EB, int EXP = 0>
 int launch_phased(const svs_index* idx, Ctx* c, int64_t n_rows, int nq, float* scores, int64_t sstride,
                   FuseLaunch fl, hipStream_t st) {
   static std::once_flag once;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute((const void*)gemm_phased_kernel<FUSE, EB>, hipFuncAttributeMaxDynamicSharedMemorySize, PG_LDS_TOTAL);
+    (void)hipFuncSetAttribute((const void*)gemm_phased_kernel<FUSE, EB, EXP>, hipFuncAttributeMaxDynamicSharedMemorySize, PG_LDS_TOTAL);
   });
   const int gx = (int)((n_rows + PG_TILE - 1) / PG_TILE), gy = (nq + PG_TILE - 1) / PG_TILE;
   const int64_t total = (int64_t)gx * gy;
   const unsigned grid = (unsigned)std::min<int64_t>(total, idx->cu_count);   // one persistent workgroup per CU
   const uint8_t* Q = EB == 2 ? (const uint8_t*)c->qh : (const uint8_t*)c->q8;
-  hipLaunchKernelGGL((gemm_phased_kernel<FUSE, EB>), dim3(grid), dim3(PG_THREADS), PG_LDS_TOTAL, st,
+  hipLaunchKernelGGL((gemm_phased_kernel<FUSE, EB, EXP>), dim3(grid), dim3(PG_THREADS), PG_LDS_TOTAL, st,
                      (const uint8_t*)idx->rows, Q, scores, n_rows, (int)(idx->ld * EB), sstride, nq, gx, gy,
                      fl.state, (int)SCR_WORDS, fl.cand, (uint32_t)CAND_CAP, fl.thr, fl.thr_stride,
                      (const float*)idx->row_scales, (const float*)c->q8s);
@@ -641,9 +641,14 @@ int launch_tiled_eb(const svs_index* idx, Ctx* c, int64_t n_rows, int nq, int bn
                     FuseLaunch fl, hipStream_t st) {
   const bool f = fl.state != nullptr;
   if constexpr (EB != 4) {
-    if (bn == 256 && !fl.pairs.on && phased_ok(idx, n_rows, nq))
+    if (bn == 256 && !fl.pairs.on && phased_ok(idx, n_rows, nq)) {
+      if (f && EB == 2 && idx->variant.load() == 8)   // A/B: LDS-DMA pieces issued with the fragment reads
+        return launch_phased<true, EB, 30>(idx, c, n_rows, nq, scores, sstride, fl, st);
+      if (f && EB == 2 && idx->variant.load() == 9)   // A/B: fused epilogue with a branch per register
+        return launch_phased<true, EB, 31>(idx, c, n_rows, nq, scores, sstride, fl, st);
       return f ? launch_phased<true, EB>(idx, c, n_rows, nq, scores, sstride, fl, st)
                : launch_phased<false, EB>(idx, c, n_rows, nq, scores, sstride, fl, st);
+    }
   }
   switch (bn) {
     case 32: return f ? launch_tiled_bn<32, true, EB>(idx, c, n_rows, nq, scores, sstride, fl, st) : launch_tiled_bn<32, false, EB>(idx, c, n_rows, nq, scores, sstride, fl, st);
@@ -1712,7 +1717,7 @@ int32_t svs_index_get_timing(svs_index* idx, svs_timing_t* out) {
 
 int32_t svs_index_set_variant(svs_index* idx, int32_t variant) {
   if (!idx) return fail(SVS_ERR_INVALID, "null index");
-  if (variant < 0 || variant > 7) return fail(SVS_ERR_INVALID, "unknown variant %d", variant);
+  if (variant < 0 || variant > 9) return fail(SVS_ERR_INVALID, "unknown variant %d", variant);
   idx->variant.store(variant);
   return SVS_OK;
 }

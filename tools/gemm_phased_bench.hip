@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <vector>
 #define PG_CLOCKS
 #include "../svs_amd/csrc/select.h"
@@ -22,6 +23,7 @@ void launch_phased(const Args& a, int cus) {
   if (!once) { CK(hipFuncSetAttribute((const void*)gemm_phased_kernel<true, EB, EXP>, hipFuncAttributeMaxDynamicSharedMemorySize, PG_LDS_TOTAL)); once = true; }
   const int gx = (int)((a.n + 255) / 256), gy = (a.nq + 255) / 256;
   const unsigned grid = (unsigned)std::min<int64_t>((int64_t)gx * gy, cus);
+  if (getenv("PGB_REAL")) CK(hipMemsetAsync(a.st, 0, (size_t)a.nq * SCR_WORDS * 4, 0));   // (the candidate lists start empty, like in a search)
   hipLaunchKernelGGL((gemm_phased_kernel<true, EB, EXP>), dim3(grid), dim3(PG_THREADS), PG_LDS_TOTAL, 0, a.M, a.Q, a.S, a.n, a.ldb, a.n, a.nq, gx, gy,
                      a.st, (int)SCR_WORDS, a.cand, (uint32_t)CAND_CAP, a.thr, 1, a.rs, a.rs);
 }
@@ -30,6 +32,7 @@ void launch_tiled(const Args& a, int) {
   static bool once = false;
   const int lds = tg_lds_bytes(256, 256);
   if (!once) { CK(hipFuncSetAttribute((const void*)gemm_tiled_kernel<256, true, EB, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); once = true; }
+  if (getenv("PGB_REAL")) CK(hipMemsetAsync(a.st, 0, (size_t)a.nq * SCR_WORDS * 4, 0));
   hipLaunchKernelGGL((gemm_tiled_kernel<256, true, EB, 256>), dim3((unsigned)((a.n + 255) / 256), (a.nq + 255) / 256), dim3(512), lds, 0,
                      a.M, a.Q, a.S, a.n, (int64_t)a.ldb, a.n, a.nq, a.st, (int)SCR_WORDS, a.cand, (uint32_t)CAND_CAP, a.thr, 1, a.rs, a.rs);
 }
@@ -61,14 +64,27 @@ int run(int64_t n, int d, int nq, int rounds) {
   const int nq_pad = (nq + 255) / 256 * 256;
   CK(hipMalloc(&a.M, n * a.ldb)); CK(hipMalloc(&a.Q, (size_t)nq_pad * a.ldb)); a.S = nullptr;
   std::vector<uint8_t> h((size_t)64 << 20);
+  // PGB_REAL=1 (f16): rows like the parity corpus -- Gaussian, unit norm in expectation -- and the thresholds the
+  // prefix pass would hand the epilogue (k = 100 of n / 64 rows: 2.49 sigma), ~420 survivors per output tile
+  const bool real = getenv("PGB_REAL") && EB == 2;
   for (size_t i = 0; i < h.size(); ++i) h[i] = (uint8_t)(rand() & (EB == 2 ? ((i & 1) ? 0xa7 : 0xff) : 0xb7));   // exponent bits kept small
+  if (real) {
+    _Float16* hh = (_Float16*)h.data();
+    const float sd = 1.0f / sqrtf((float)d);
+    uint64_t x = 88172645463325252ull;
+    auto u01 = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return (float)((x >> 11) * (1.0 / 9007199254740992.0)) + 1e-12f; };
+    for (size_t i = 0; i + 1 < h.size() / 2; i += 2) {
+      const float r = sqrtf(-2.f * logf(u01())), t = 6.2831853f * u01();
+      hh[i] = (_Float16)(sd * r * cosf(t)); hh[i + 1] = (_Float16)(sd * r * sinf(t));
+    }
+  }
   for (size_t off = 0; off < (size_t)(n * a.ldb); off += h.size()) CK(hipMemcpy(a.M + off, h.data(), std::min(h.size(), (size_t)(n * a.ldb) - off), hipMemcpyHostToDevice));
   CK(hipMemcpy(a.Q, h.data() + 12346, (size_t)nq_pad * a.ldb, hipMemcpyHostToDevice));   // (an EVEN offset: the exponent mask sits on the odd bytes; an odd one fills the queries with inf / NaN)
   CK(hipMalloc(&a.st, (size_t)nq * SCR_WORDS * 4)); CK(hipMemset(a.st, 0, (size_t)nq * SCR_WORDS * 4));
   CK(hipMalloc(&a.cand, (size_t)nq * CAND_CAP * 8)); CK(hipMalloc(&a.thr, nq * 4)); CK(hipMalloc(&a.rs, n * 4)); CK(hipMemset(a.rs, 0, n * 4));
-  { std::vector<float> t(nq, 1e30f); CK(hipMemcpy(a.thr, t.data(), nq * 4, hipMemcpyHostToDevice)); }
+  { std::vector<float> t(nq, real ? 2.49f / sqrtf((float)d) : 1e30f); CK(hipMemcpy(a.thr, t.data(), nq * 4, hipMemcpyHostToDevice)); }
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
-  const int cus = prop.multiProcessorCount;
+  const int cus = getenv("PGB_CUS") ? atoi(getenv("PGB_CUS")) : prop.multiProcessorCount;   // (PGB_CUS: fewer workgroups, the same work each: per-CU rates)
   // every phased launch stamps its clocks: the buffer must exist before the first one
   unsigned long long* cb; CK(hipMalloc(&cb, (size_t)std::max(cus, 256) * 8 * 8)); CK(hipMemset(cb, 0, (size_t)std::max(cus, 256) * 8 * 8));
   CK(hipMemcpyToSymbol(HIP_SYMBOL(pg_clock_buf), &cb, sizeof(cb)));
@@ -77,7 +93,7 @@ int run(int64_t n, int d, int nq, int rounds) {
   struct V { const char* name; Fn fn; };
   const V vs[] = {{"round-1 tiled 256x256", launch_tiled<EB>}, {"phased", launch_phased<EB, 0>}, {"phased, no LDS-DMA in loop", launch_phased<EB, 1>},
                   {"phased, no fragment reads", launch_phased<EB, 2>}, {"phased, no MFMA", launch_phased<EB, 3>},
-                  {"phased, no stagger", launch_phased<EB, 7>}, {"phased, no epilogue", launch_phased<EB, 14>}};
+                  {"phased, no stagger", launch_phased<EB, 7>}, {"phased, LDS-DMA + barriers only", launch_phased<EB, 5>}, {"phased, DMA pieces with the reads", launch_phased<EB, 30>}, {"phased, always k-tile 0 (L2 hits)", launch_phased<EB, 21>}, {"phased, DMA + barriers only, always k-tile 0", launch_phased<EB, 25>}, {"phased, barriers only", launch_phased<EB, 26>}, {"phased, epilogue with a branch per register", launch_phased<EB, 31>}, {"phased, no epilogue", launch_phased<EB, 14>}};
   const int NVALL = sizeof(vs) / sizeof(vs[0]);
   const char* only = getenv("PGB_ONLY");          // e.g. PGB_ONLY=2 runs variant 2 alone (fault hunting)
   V sel[16]; int NV = 0;

@@ -54,6 +54,22 @@ int run(int64_t n, int d, int nq) {
              s0 - prev, s1 - s0, s2 - s1, s3 - s2, s0, s1, s2, s3);
     }
   }
+  // barrier view: global barrier b is (phase, barrier 1) = 2 ph, (phase, barrier 2) = 2 ph + 1 for waves 0-3 and one
+  // later for waves 4-7.  Arrival of every wave (cycles before the LAST arrival), and release - last arrival.
+  printf(" barriers: arrival of waves 0..7 relative to the last one to arrive | release after the last arrival (min over waves)\n");
+  for (int b = 1; b < 2 * PG_TRACE_KTS * 4 - 1; ++b) {
+    long long arr[8], rel[8];
+    for (int w = 0; w < 8; ++w) {
+      const int bb = w < 4 ? b : b - 1, ph = bb >> 1, second = bb & 1;
+      arr[w] = at(w, ph, second ? 2 : 0) - base;
+      rel[w] = at(w, ph, second ? 3 : 1) - base;   // (barrier 1: includes the wait for the fragments)
+    }
+    long long last = arr[0], first_rel = rel[0];
+    for (int w = 1; w < 8; ++w) { last = std::max(last, arr[w]); first_rel = std::min(first_rel, rel[w]); }
+    printf("   b %2d (A: ph %d b%d): ", b, (b >> 1) & 3, (b & 1) + 1);
+    for (int w = 0; w < 8; ++w) printf("%5lld", arr[w] - last);
+    printf(" | %4lld   [last arrival at %6lld]\n", first_rel - last, last);
+  }
   const long long span = at(0, PG_TRACE_KTS * 4 - 1, 3) - at(0, 0, 3);
   printf(" wave 0: %lld cycles for %d phases = %lld per k-tile\n", span, PG_TRACE_KTS * 4 - 1, span * 4 / (PG_TRACE_KTS * 4 - 1));
   return 0;
