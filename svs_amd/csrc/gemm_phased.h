@@ -151,6 +151,12 @@ __device__ __forceinline__ void pg_park_if(unsigned& ak, float v, float thr, uin
       : "vcc", "memory");
 }
 
+__device__ __forceinline__ int pg_voff(int vbase, int uniform_bytes) {
+  int vo;
+  asm volatile("v_add_u32_e32 %0, %1, %2" : "=v"(vo) : "s"(uniform_bytes), "v"(vbase));
+  return vo;
+}
+
 struct PgTile {
   __amdgpu_buffer_rsrc_t a, b;   // corpus rows / query rows of the tile
   int64_t row0;
@@ -224,6 +230,11 @@ __device__ __forceinline__ float pg_lds_read_f32(unsigned adr) {
   asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(adr) : "memory");
   return v;
 }
+__device__ __forceinline__ f32x4_t pg_lds_read_f32x4(unsigned adr) {
+  f32x4_t v;
+  asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(adr) : "memory");
+  return v;
+}
 __device__ __forceinline__ uint32_t pg_lds_read_u32(unsigned adr) {
   uint32_t v;
   asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(adr) : "memory");
@@ -266,19 +277,17 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
   const int my_tiles = __builtin_amdgcn_readfirstlane((total - (int)blockIdx.x + G - 1) / G);
 
   // ---- per-lane constants of the staging side: byte offset of the lane's 16 bytes inside a tile
-  int voffA[2][2], voffB[2][2];                      // [half][instruction]
+  // ONE register: the 16 bytes of row li0 = 8 wave + lane / 8 of a tile.  The eight (operand, half, instruction)
+  // pieces a wave stages differ from it by whole rows, the same for every lane:
+  //   A half h, instruction jj: row (li >> 6) * 128 + h * 64 + (li & 63) with li = li0 + 64 jj  =  li0 + jj * 128 + h * 64
+  //   B half h, instruction jj: row (li >> 5) * 64 + h * 32 + (li & 31)                         =  li0 + (wave >> 2) * 32 + jj * 128 + h * 32
+  // (the swizzle depends on bits 1-3 of li only).  The row part must stay in the VECTOR offset -- the descriptor's
+  // range check does not see soffset -- so each piece adds its scalar to the base just before it is issued
+  // (pg_voff: one v_add, volatile so that hipcc does not hoist the eight sums back into eight live registers).
+  int vbase;
   {
-    const int r_in = lane >> 3, pc = lane & 7;
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-      const int li = 8 * (wave + 8 * jj) + r_in;     // row of the half-tile image this lane fills
-      const int ch = (pc ^ tg_swz(li)) * 16;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        voffA[h][jj] = ((li >> 6) * 128 + h * 64 + (li & 63)) * ldb + ch;
-        voffB[h][jj] = ((li >> 5) * 64 + h * 32 + (li & 31)) * ldb + ch;
-      }
-    }
+    const int li0 = 8 * wave + (lane >> 3), pc = lane & 7;
+    vbase = li0 * ldb + (pc ^ tg_swz(li0)) * 16;
   }
   // ---- ... and of the reading side: LDS byte address of the lane's 16 bytes in slot 0 / slot 4
   // (pg_read_a / pg_read_b)
@@ -323,7 +332,8 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
     constexpr bool next = decltype(NEXT)::value != 0;
     const int soff = (EXP == 21 || EXP == 25) ? 0 : kt * TG_BKB;   // (ablation 21: always the first k-tile: L2 hits)
     const __amdgpu_buffer_rsrc_t rs = (kind & 1) ? (next ? nxt.a : cur.a) : (next ? nxt.b : cur.b);
-    const int vo = (kind & 1) ? voffA[kind >> 1][jj] : voffB[kind >> 1][jj];
+    const int rows = (kind & 1) ? jj * 128 + (kind >> 1) * 64 : wr * 32 + jj * 128 + (kind >> 1) * 32;
+    const int vo = pg_voff(vbase, rows * ldb);
     if constexpr (EXP == 20 && (kind & 1))   // (ablation: corpus rows nontemporal)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(pg_lds + slot * PG_SLOT + (wave + 8 * jj) * 64),
                                                16, vo, soff, 0, 2);
@@ -475,10 +485,16 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
   uint32_t fslot[2] = {0u, 0u};
   int f_pp = 0, f_q0 = 0;     // wave-uniform
   int64_t f_row0 = 0;
+  // (tid / lane copies behind an empty asm: what the flush and the epilogue derive from them is recomputed per
+  //  tile -- a handful of ALU instructions -- instead of being computed once, kept live across the k loop and,
+  //  the register file being full there, spilled: every reload of a spilled VGPR waits vmcnt(0), i.e. for the
+  //  whole LDS-DMA ring)
   auto flush_a = [&]() {
+    int tid = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid));
 #pragma unroll
     for (int r = 0; r < PG_PARK / PG_THREADS; ++r) {
-      const int e = (int)threadIdx.x + r * PG_THREADS, w = e / (PG_PARK / 8), i = e % (PG_PARK / 8);
+      const int e = tid + r * PG_THREADS, w = e / (PG_PARK / 8), i = e % (PG_PARK / 8);
       const uint32_t nw = pg_lds_read_u32(PG_SIDE_CNT + (f_pp * 8 + w) * 4);
       if ((uint32_t)i < nw) {
         const uint32_t code = pg_lds_read_u32(PG_SIDE_KEY + (f_pp * PG_PARK + e) * 8 + 4);
@@ -491,9 +507,11 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
   auto flush_b = [&](bool waited) {
     if (!waited) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(fslot[0]), "+v"(fslot[1]) : "n"(PG_VMCNT) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" : "+v"(fslot[0]), "+v"(fslot[1])::"memory");
+    int tid = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid));
 #pragma unroll
     for (int r = 0; r < PG_PARK / PG_THREADS; ++r) {
-      const int e = (int)threadIdx.x + r * PG_THREADS, w = e / (PG_PARK / 8), i = e % (PG_PARK / 8);
+      const int e = tid + r * PG_THREADS, w = e / (PG_PARK / 8), i = e % (PG_PARK / 8);
       const uint32_t nw = pg_lds_read_u32(PG_SIDE_CNT + (f_pp * 8 + w) * 4);
       if ((uint32_t)i < nw && fslot[r] < fcap) {
         const uint64_t sc = pg_lds_read_u64(PG_SIDE_KEY + (f_pp * PG_PARK + e) * 8);   // (score bits, code)
@@ -507,6 +525,9 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
   // ---- epilogue of one tile: scales (fp8), then scores out (materialised) or candidates parked
   auto epilogue = [&](const PgTile& t, int par) {
     const int wrow = wr * 128, wq = wc * 64;
+    int lane_e = (int)threadIdx.x & 63;
+    asm volatile("" : "+v"(lane_e));
+    const int lane = lane_e, r16 = lane_e & 15, g = lane_e >> 4;   // (shadow the kernel's: see flush_a)
     if constexpr (!FUSE) {
       // (rows / queries past the ends are not stored; fp8 scales are applied by tg_epilogue's own loads: this
       //  path is the prefix pass and set_variant(6), not the hot one)
@@ -523,6 +544,26 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
       // ordered by similarity to a query, or a query made of NaNs: every score survives).
       const int lr0 = wrow + 4 * g;                                        // the lane's first row inside the tile
       const int lim = (int)(n - t.row0 < PG_TILE ? n - t.row0 : PG_TILE);  // live rows of this tile
+      if constexpr (EB == 1) {   // per-row and per-query dequantisation scales, applied in place (as tg_epilogue: v * (rs * qs))
+        float qs[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) qs[j] = pg_lds_read_f32(PG_SIDE_QS + par * 1024 + (wq + j * 16 + r16) * 4);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const f32x4_t rs = pg_lds_read_f32x4(PG_SIDE_RS + par * 1024 + (lr0 + i * 16) * 4);
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              // (in place by construction: left to hipcc the 128 products go to new registers, the accumulator
+              //  quads stay live until their last element is read, and ~50 values spill)
+              float v = acc[i][j][r];
+              const float sc = rs[r] * qs[j];
+              asm volatile("v_mul_f32_e32 %0, %1, %0" : "+v"(v) : "v"(sc));
+              acc[i][j][r] = v;
+            }
+        }
+      }
       constexpr int WCAP = PG_PARK / 8;
       const unsigned kadr = PG_SIDE_KEY + (par * PG_PARK + wave * WCAP) * 8;
       int wcount = 0;   // wave-uniform
@@ -537,8 +578,6 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
           //  kernel entry and spills them -- ~500 registers' worth of scratch traffic behind vmcnt(0) waits)
           uint32_t cbase = (uint32_t)(lr0 | (ql << 8));
           asm volatile("" : "+v"(cbase));
-          float qs = 1.f;
-          if constexpr (EB == 1) qs = pg_lds_read_f32(PG_SIDE_QS + par * 1024 + ql * 4);
 #pragma unroll
           for (int i = 0; i < MT; ++i) {
             // the four compares of a tile first (their lane masks land in scalar registers: a
@@ -548,7 +587,6 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               v[r] = acc[i][j][r];
-              if constexpr (EB == 1) v[r] *= qs * pg_lds_read_f32(PG_SIDE_RS + par * 1024 + (lr0 + i * 16 + r) * 4);
               // lanes whose score is not below the threshold (unordered-or-greater-equal: a NaN passes)
               mask[r] = __builtin_amdgcn_fcmpf(v[r], thr, 11 /* FCMP_UGE */);
               if constexpr (!qall) mask[r] &= qokm;
@@ -590,12 +628,7 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
           thr[j] = pg_lds_read_f32(PG_SIDE_THR + par * 1024 + ql * 4);
           base[j] = (uint32_t)(lr0 | (ql << 8));
         }
-        auto val = [&](int i, int j, int r) {
-          float v = acc[i][j][r];
-          if constexpr (EB == 1)
-            v *= pg_lds_read_f32(PG_SIDE_QS + par * 1024 + (wq + j * 16 + r16) * 4) * pg_lds_read_f32(PG_SIDE_RS + par * 1024 + (lr0 + i * 16 + r) * 4);
-          return v;
-        };
+        auto val = [&](int i, int j, int r) { return acc[i][j][r]; };
         uint32_t cnt = 0;
 #pragma unroll
         for (int j = 0; j < NT; ++j)

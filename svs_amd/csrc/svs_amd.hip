@@ -632,7 +632,7 @@ int launch_phased(const svs_index* idx, Ctx* c, int64_t n_rows, int nq, float* s
 // and tile counts inside 32-bit descriptors / ints
 bool phased_ok(const svs_index* idx, int64_t n_rows, int nq) {
   const int64_t ldb = (int64_t)idx->ld * (int64_t)elem_bytes(idx);
-  return idx->variant.load() != 2 && idx->dtype == SVS_DTYPE_F16 && ldb % (2 * TG_BKB) == 0 && ldb >= PG_MIN_KT * TG_BKB && ldb <= (1 << 20) &&
+  return idx->variant.load() != 2 && (idx->dtype == SVS_DTYPE_F16 || idx->dtype == SVS_DTYPE_FP8) && ldb % (2 * TG_BKB) == 0 && ldb >= PG_MIN_KT * TG_BKB && ldb <= (1 << 20) &&
          ((n_rows + PG_TILE - 1) / PG_TILE) * ((nq + PG_TILE - 1) / PG_TILE) < (1ll << 30);
 }
 
@@ -642,9 +642,9 @@ int launch_tiled_eb(const svs_index* idx, Ctx* c, int64_t n_rows, int nq, int bn
   const bool f = fl.state != nullptr;
   if constexpr (EB != 4) {
     if (bn == 256 && !fl.pairs.on && phased_ok(idx, n_rows, nq)) {
-      if (f && EB == 2 && idx->variant.load() == 8)   // A/B: LDS-DMA pieces issued with the fragment reads
+      if (f && idx->variant.load() == 8)   // A/B: LDS-DMA pieces issued with the fragment reads
         return launch_phased<true, EB, 30>(idx, c, n_rows, nq, scores, sstride, fl, st);
-      if (f && EB == 2 && idx->variant.load() == 9)   // A/B: fused epilogue with a branch per register
+      if (f && idx->variant.load() == 9)   // A/B: fused epilogue with a branch per register
         return launch_phased<true, EB, 31>(idx, c, n_rows, nq, scores, sstride, fl, st);
       return f ? launch_phased<true, EB>(idx, c, n_rows, nq, scores, sstride, fl, st)
                : launch_phased<false, EB>(idx, c, n_rows, nq, scores, sstride, fl, st);
