@@ -51,12 +51,15 @@ constexpr int PG_SLOT = 1024;             // u32x4 per slot (16 KiB)
 constexpr int PG_LDS_BYTES = 8 * PG_SLOT * 16;
 constexpr int PG_THREADS = 512;
 
-// PG_DMA_IN_MMA: a phase's two LDS-DMA pieces are issued between its MFMAs (after MFMA pair
+// PG_DMA_IN_MMA = 1: a phase's two LDS-DMA pieces are issued between its MFMAs (after MFMA pair
 // PG_DMA_AT0 of the first k half and PG_DMA_AT1 of the second) instead of with its fragment reads.
 // The stream then runs half a phase later: at a phase's counted wait the youngest half-tile in
 // flight is P + 6, and "everything up to P + 2" is all but the FOUR youngest half-tiles: vmcnt(8).
+// Measured on real data the two placements are within 2 % of each other (configs[2]: 2.42-2.50 ms
+// with the reads, 2.44-2.62 between the MFMAs; configs[4]: 7.17 vs 7.19): the default issues them
+// with the reads, svs_index_set_variant(8) selects the other (tools/cfg_time.py).
 #ifndef PG_DMA_IN_MMA
-#define PG_DMA_IN_MMA 1
+#define PG_DMA_IN_MMA 0
 #endif
 #ifndef PG_DMA_STAGGER
 #define PG_DMA_STAGGER 0
@@ -376,10 +379,7 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
     for (int i = 0; i < 2; ++i) fb0[i][0] = fb0[i][1] = fb1[i][0] = fb1[i][1] = c;
   }
   // one quadrant: rows 64 i .. 64 i + 63, queries 32 j .. 32 j + 31 of the wave tile
-  // s0 / s1: the phase's two LDS-DMA pieces, issued BETWEEN the MFMAs (PG_DMA_IN_MMA): beside bare
-  // MFMAs a piece costs the wave ~60 cycles of issue, inside the reading segment (12 ds_read_b128
-  // of four waves in flight) 100-185 (MI355X_MICROARCH.md, timing table) -- and the reading
-  // segment, not the MFMAs, was what set the barrier interval (~460 cycles for 256 of MFMA)
+  // s0 / s1: the phase's two LDS-DMA pieces when they are issued BETWEEN the MFMAs (kDmaInMma)
   auto mma = [&](auto I, auto J, const u32x4 (&fb)[2][2], auto&& s0, auto&& s1) {
     constexpr int i = decltype(I)::value, j = decltype(J)::value;
     if constexpr (EB == 2) {
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
   };
 #define PG_C(v) std::integral_constant<int, (v)>{}
   constexpr bool kStage = EXP != 1 && EXP != 26, kRead = EXP != 2 && EXP != 5 && EXP != 25 && EXP != 26, kMma = EXP != 3 && EXP != 5 && EXP != 25 && EXP != 26;   // (26: barriers only)   // (EXP 5: LDS-DMA and barriers only)
-  constexpr bool kDmaInMma = PG_DMA_IN_MMA && EXP != 30;   // (EXP 30: pieces issued with the fragment reads, A/B)
+  constexpr bool kDmaInMma = (PG_DMA_IN_MMA != 0) != (EXP == 30);   // (EXP 30: the other placement, A/B)
   // what follows the loads of a phase: [retire the B reads] wait for the NEXT phase's data, barrier,
   // fragments in, 16 MFMAs at raised priority (keeps hipcc from moving them over the barriers), barrier
 #define PG_SYNC_AND_MMA(PH, I, J, FB, LGKM8, LAND, KIND, SLOT, NEXT, KT_)    \

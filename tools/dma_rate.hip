@@ -69,7 +69,65 @@ void run(const char* name, const uint8_t* src, unsigned long long* out, int wgs,
          (double)h[wgs / 2] / (iters * DEPTH * waves));
 }
 
+// HBM streaming: every workgroup reads `tiles` consecutive 256-row tiles ONCE (nothing is reused), LDS-DMA, DEPTH
+// instructions in flight per wave.  PANEL == 0: the corpus is row-major (a k-tile of a row tile = 256 pieces of
+// 128 B at a row stride of ldb bytes, what gemm_phased streams); PANEL == 1: tile-major (the k-tile is one
+// contiguous 32 KiB block).
+template <int PANEL, int DEPTH>
+__global__ __launch_bounds__(512) void hbm_stream(const uint8_t* src, unsigned long long* out, int tiles, int ldb) {
+  extern __shared__ u32x4 lds[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const size_t tile_bytes = (size_t)256 * ldb;
+  const int KT = ldb / 128;
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int t = 0; t < tiles; ++t) {
+    const uint8_t* base = src + ((size_t)blockIdx.x * tiles + t) * tile_bytes;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)tile_bytes, 0x00020000);
+    for (int kt = 0; kt < KT; kt += DEPTH / 4) {
+#pragma unroll
+      for (int j = 0; j < DEPTH; ++j) {            // 4 instructions of a wave per k-tile (8 waves x 4 KiB = 32 KiB)
+        const int k = kt + j / 4, piece = wave * 4 + (j & 3);   // piece: 8 rows (row-major) or 1 KiB (tile-major)
+        int vo, so;
+        if constexpr (PANEL == 0) { vo = (piece * 8 + (lane >> 3)) * ldb + (lane & 7) * 16; so = k * 128; }
+        else { vo = piece * 1024 + lane * 16; so = k * 32768; }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lds + (j * 8 + wave) * 64), 16, vo, so, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEPTH / 2) : "memory");
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
+}
+template <int PANEL, int DEPTH>
+void run_hbm(const char* name, const uint8_t* src, unsigned long long* out, int tiles, int ldb) {
+  CK(hipFuncSetAttribute((const void*)hbm_stream<PANEL, DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  float best = 1e30f;
+  for (int rep = 0; rep < 3; ++rep) {
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((hbm_stream<PANEL, DEPTH>), dim3(256), dim3(512), 131072, 0, src, out, tiles, ldb);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = std::min(best, ms);
+  }
+  const double bytes = 256.0 * tiles * 256 * ldb;
+  printf("  %-40s depth %2d: %6.2f TB/s (%.2f ms for %.1f GB)\n", name, DEPTH, bytes / (best * 1e-3) / 1e12, best, bytes / 1e9);
+}
+
 int main(int argc, char** argv) {
+  if (argc > 1 && atoi(argv[1]) == 0) {   // dma_rate 0: HBM streaming patterns
+    const int ldb = 3072, tiles = 48;     // 256 workgroups x 48 tiles x 768 KiB = 9.66 GB
+    uint8_t* src; unsigned long long* out;
+    CK(hipMalloc(&src, (size_t)256 * tiles * 256 * ldb)); CK(hipMemset(src, 1, (size_t)256 * tiles * 256 * ldb)); CK(hipMalloc(&out, 256 * 8));
+    printf("HBM streaming, 256 workgroups, LDS-DMA, every byte read once\n");
+    run_hbm<0, 8>("row-major: 8 rows x 128 B per piece", src, out, tiles, ldb);
+    run_hbm<0, 16>("row-major: 8 rows x 128 B per piece", src, out, tiles, ldb);
+    run_hbm<1, 8>("tile-major: 1 KiB contiguous per piece", src, out, tiles, ldb);
+    run_hbm<1, 16>("tile-major: 1 KiB contiguous per piece", src, out, tiles, ldb);
+    return 0;
+  }
   const int wgs = argc > 1 ? atoi(argv[1]) : 256, waves = argc > 2 ? atoi(argv[2]) : 8, ldb = 3072, windows = argc > 3 ? atoi(argv[3]) : 32;
   uint8_t* src; unsigned long long* out;
   CK(hipMalloc(&src, (size_t)wgs * 256 * ldb)); CK(hipMemset(src, 1, (size_t)wgs * 256 * ldb)); CK(hipMalloc(&out, wgs * 8));
