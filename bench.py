@@ -22,6 +22,7 @@ the dominant kernel / its HIP-event-measured duration; cpu_baseline = the numpy
 restatement of the reference path (oracle/) timed on this host's cores.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -38,7 +39,7 @@ KERNEL_NAME = {  # dominant kernel per dtype and batch shape (svs_amd/csrc)
     ("f32", 1): "gemv_f32_oneshot_kernel (gemv_f32.h)", ("f16", 1): "gemv_f16_oneshot_kernel (gemv_f16.h)",
     ("fp8", 1): "gemv_fp8_oneshot_kernel (fp8.h)", ("f32", 16): "gemm_q16r_kernel<FUSE, 4> (gemm_q16.h)",
     ("f32", 256): "gemm_tiled_kernel<64, FUSE, 4> (gemm_tiled.h)", ("f16", 1024): "gemm_phased_kernel<FUSE, 2> (gemm_phased.h)",
-    ("fp8", 256): "gemm_tiled_kernel<256, FUSE, 1, 256> (gemm_tiled.h)",
+    ("fp8", 256): "gemm_phased_kernel<FUSE, 1> (gemm_phased.h)",
 }
 
 
@@ -71,6 +72,19 @@ def batched_config(torch, idx, name, n, d, dtype, nq, k, seed, reps):
                         "algorithmic_flops_per_launch": flops, "avg_launch_ms": dom_ms, "launches_timed": cnt,
                         "traffic": None},
            "note": "host API (queries in, results out, synchronised); kernel time from HIP events inside the library"}
+    # HBM bytes of that kernel from the committed FETCH_SIZE pass (tools/profile_round.sh), if there is one
+    cfg_tag = {("f16", 1024): "cfg2", ("fp8", 256): "cfg4"}.get((dtype, nq))
+    if cfg_tag:
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{cfg_tag}_summary.json")), reverse=True):
+            try:
+                pm = json.load(open(f)).get("pmc", {})
+                hit = [v["hbm_read_bytes_per_launch"] for kn, v in pm.items() if "gemm_phased_kernel<true" in kn and "hbm_read_bytes_per_launch" in v]
+                if hit:
+                    out["roofline"]["traffic"] = hit[0]
+                    out["roofline"]["traffic_source"] = os.path.relpath(f, ROOT) + " (FETCH_SIZE x 2, reads only)"
+                    break
+            except Exception:
+                pass
     if dtype == "fp8":   # mixed bound, both fractions
         out["roofline_hbm"] = {"bound": "hbm", "achieved": bytes_ / (dom_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                                "frac": bytes_ / (dom_ms * 1e-3) / HBM_PEAK, "algorithmic_bytes_per_launch": bytes_}

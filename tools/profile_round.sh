@@ -2,7 +2,7 @@
 # Regenerates the rocprofv3 evidence under gpurun_out/prof_<tag>_* (run on the GPU box through
 # gpurun, from the repo root); tools/summarize_prof.py / summarize_cfg.py then condense it into
 # profiles/.  Counters are collected in their own passes, with --kernel-trace only.
-#   usage: tools/profile_round.sh r1 [a|b]     (a: configs[1], batch-16, configs[2];  b: configs[4])
+#   usage: tools/profile_round.sh r1 [a|b|c|ab]   (a: configs[1], batch-16;  c: configs[2];  b: configs[4])
 set -e -o pipefail
 tag=${1:-r1}
 part=${2:-ab}
@@ -18,13 +18,17 @@ run write --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/prof_${tag}_
 # batched f32, 16 queries per call
 run b16_trace --kernel-trace --stats --output-format csv -d $O/prof_${tag}_b16_trace -- python3 $R/tools/prof_batch.py 1000000 1536 f32 16 20 > /dev/null
 run b16_fetch --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/prof_${tag}_b16_fetch -- python3 $R/tools/prof_batch.py 1000000 1536 f32 16 6 > /dev/null
+fi
+if [[ $part == *c* || $part == *a* ]]; then
 # configs[2]: f16, 1024 queries per call
-run cfg2_trace --kernel-trace --stats --output-format csv -d $O/prof_${tag}_cfg2_trace -- python3 $R/tools/prof_batch.py 1000000 1536 f16 1024 6 > /dev/null
+run cfg2_trace --kernel-trace --stats --output-format csv -d $O/prof_${tag}_cfg2_trace -- python3 $R/tools/prof_batch.py 1000000 1536 f16 1024 24 > /dev/null
+run cfg2_fetch --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/prof_${tag}_cfg2_fetch -- python3 $R/tools/prof_batch.py 1000000 1536 f16 1024 4 > /dev/null
 run cfg2_pmc --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CU_CYCLES --output-format csv -d $O/prof_${tag}_cfg2_pmc -- python3 $R/tools/prof_batch.py 1000000 1536 f16 1024 3 > /dev/null
 fi
 if [[ $part == *b* ]]; then
 # configs[4]: fp8 10M x 3072, 256 queries per call
-run cfg4_trace --kernel-trace --stats --output-format csv -d $O/prof_${tag}_cfg4_trace -- python3 $R/tools/prof_batch.py 10000000 3072 fp8 256 4 > /dev/null
+run cfg4_trace --kernel-trace --stats --output-format csv -d $O/prof_${tag}_cfg4_trace -- python3 $R/tools/prof_batch.py 10000000 3072 fp8 256 12 > /dev/null
+run cfg4_fetch --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/prof_${tag}_cfg4_fetch -- python3 $R/tools/prof_batch.py 10000000 3072 fp8 256 3 > /dev/null
 run cfg4_pmc --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CU_CYCLES --output-format csv -d $O/prof_${tag}_cfg4_pmc -- python3 $R/tools/prof_batch.py 10000000 3072 fp8 256 2 > /dev/null
 fi
 echo "[profile_round] all passes done"
