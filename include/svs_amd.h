@@ -195,6 +195,29 @@ int32_t svs_index_scores(svs_index* idx, const float* query, int32_t d, float* o
 int32_t svs_index_top_pairs(svs_index* idx, int32_t k, float* out_scores, int64_t* out_i, int64_t* out_j,
                             int32_t* out_count);
 
+/* ---- one process, several GPUs: the `devices, ndev` form of the create/search pair (SURVEY.md
+ *      8(b), 8(e)).  Replaces the same reference lines as svs_index_create / svs_index_search
+ *      (src/svs/kb.py:875-876, :1623-1626, src/svs/util.py:190-203) for a KB process that owns a whole
+ *      node: the (n, d) matrix is row-sharded, shard g = rows [g * ceil(n / ndev), ...) on devices[g]
+ *      (a device may be listed more than once); a search runs on every shard at once (one worker
+ *      thread per shard inside the library), each returns its local top-k with GLOBAL rows, and the
+ *      calling thread merges them under the same total order -- scores, rows and order are those of
+ *      ONE index over the whole matrix, for any ndev.  No RCCL: the exchange is ndev * k * 12 bytes
+ *      of host memory.  Reference counted and re-entrant like svs_index. ------------------------- */
+typedef struct svs_multi svs_multi;
+int32_t svs_multi_create(const float* host_rows, int64_t n, int32_t d, int32_t store_dtype,
+                         const int32_t* devices, int32_t ndev, svs_multi** out);
+/* Same contract as svs_index_search (count = min(max(k, 0), live rows of ALL shards)). */
+int32_t svs_multi_search(svs_multi* m, const float* queries, int32_t nq, int32_t d, int32_t k,
+                         float* out_scores, int64_t* out_rows, int32_t* out_count);
+int32_t svs_multi_retain(svs_multi* m);
+int32_t svs_multi_release(svs_multi* m);
+/* Shard count, total rows (masked ones included), dimension, masked rows; any pointer may be NULL. */
+int32_t svs_multi_info(svs_multi* m, int32_t* ndev, int64_t* n, int32_t* d, int64_t* n_masked);
+/* Shard g as an ordinary index handle (one more reference: release it with svs_index_release),
+ * e.g. for svs_index_mask_rows / svs_index_info on the shard that holds a row. */
+int32_t svs_multi_shard(svs_multi* m, int32_t g, svs_index** out);
+
 /* ---- parity support (tests): what the index really holds -------------------- */
 /* Rows [row0, row0 + nrows) exactly as stored, dequantised to f32 (nrows x d,
  * C-contiguous, host).  f32: the rows; f16: half-rounded; fp8: e4m3 * row scale. */

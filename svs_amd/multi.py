@@ -175,3 +175,92 @@ class MultiDeviceIndex:
 
     def stored_query(self, query_vec: np.ndarray) -> np.ndarray:
         return self._shards[0].stored_query(query_vec)
+
+
+class NativeMultiIndex:
+    """The same thing behind the C ABI (``svs_multi_*``, include/svs_amd.h): sharding, the per-shard
+    worker threads and the merge live in the library, so a caller that is not Python gets them too.
+    Search surface of ``DeviceIndex`` (search, search_batch, shape, release)."""
+
+    def __init__(self, matrix: np.ndarray, devices: Sequence[int] = (0,), dtype: str = "f32"):
+        import ctypes as C
+        from . import _native
+        from .index import _DTYPES
+        m = np.ascontiguousarray(matrix, dtype=np.float32)
+        if m.ndim != 2:
+            raise ValueError(f"embeddings matrix must be 2-D, got shape {m.shape}")
+        self._lib = _native.load()
+        self._C, self._native = C, _native
+        dev = (C.c_int32 * len(devices))(*[int(x) for x in devices])
+        out = C.c_void_p()
+        _native.check(self._lib.svs_multi_create(m.ctypes.data_as(C.c_void_p) if m.size else None, m.shape[0], m.shape[1],
+                                                 _DTYPES[dtype], dev, len(devices), C.byref(out)))
+        self._h = out.value
+        self.d, self.dtype = int(m.shape[1]), dtype
+
+    def _info(self):
+        C = self._C
+        g, n, d, dead = C.c_int32(), C.c_int64(), C.c_int32(), C.c_int64()
+        self._native.check(self._lib.svs_multi_info(self._h, C.byref(g), C.byref(n), C.byref(d), C.byref(dead)))
+        return g.value, n.value, d.value, dead.value
+
+    @property
+    def n(self) -> int:
+        return self._info()[1]
+
+    @property
+    def shape(self) -> Tuple[int, int]:
+        return (self.n, self.d)
+
+    def search_batch(self, queries: np.ndarray, n: int) -> Tuple[np.ndarray, np.ndarray]:
+        assert isinstance(n, int)
+        C = self._C
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim != 2:
+            raise ValueError(f"queries must be 2-D, got shape {q.shape}")
+        _, rows, _, dead = self._info()
+        k = min(max(n, 0), max(rows - dead, 0), 2 ** 31 - 1)
+        scores = np.empty((q.shape[0], k), dtype=np.float32)
+        out_rows = np.empty((q.shape[0], k), dtype=np.int64)
+        count = C.c_int32(0)
+        self._native.check(self._lib.svs_multi_search(self._h, q.ctypes.data_as(C.c_void_p), q.shape[0], q.shape[1], k,
+                                                      scores.ctypes.data_as(C.c_void_p), out_rows.ctypes.data_as(C.c_void_p), C.byref(count)))
+        return scores[:, :count.value], out_rows[:, :count.value]
+
+    def search(self, query_vec: np.ndarray, n: int) -> List[Tuple[float, int]]:
+        assert isinstance(n, int)
+        q = np.asarray(query_vec, dtype=np.float32)
+        if q.ndim != 1:
+            raise ValueError(f"query must be 1-D, got shape {q.shape}")
+        s, r = self.search_batch(q[None, :], n)
+        return [(float(a), int(b)) for a, b in zip(s[0], r[0])]
+
+    def mask_rows(self, rows) -> None:
+        """Tombstones GLOBAL rows: each goes to the shard that holds it."""
+        C = self._C
+        g, n, _, _ = self._info()
+        per = (n + g - 1) // g if g else 0
+        by_shard = {}
+        for r in rows:
+            by_shard.setdefault(min(int(r) // per, g - 1) if per else 0, []).append(int(r))
+        for sg, rr in by_shard.items():
+            h = C.c_void_p()
+            self._native.check(self._lib.svs_multi_shard(self._h, sg, C.byref(h)))
+            try:
+                glob = np.asarray(rr, dtype=np.int64)   # (svs_index_mask_rows takes global rows: the shard knows its offset)
+                self._native.check(self._lib.svs_index_mask_rows(h, glob.ctypes.data_as(C.c_void_p), len(glob)))
+            finally:
+                self._lib.svs_index_release(h)
+
+    def release(self) -> None:
+        if self._h:
+            self._lib.svs_multi_release(self._h)
+            self._h = None
+
+    close = release
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
