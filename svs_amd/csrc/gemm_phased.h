@@ -303,7 +303,7 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
     adrB[1][h] = adrB[0][h] + 65536u;
   }
 
-  auto tile_desc = [&](int j) {
+  auto tile_desc = [&](int j) __attribute__((always_inline)) {
     PgTile t;
     if (j < my_tiles) {
       int bx, by;
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
 
   // kind: 0 = B0, 1 = A0, 2 = B1, 3 = A1.  NEXT: the half-tile belongs to the next output tile
   // (a compile-time fact: only the last two k-tiles of a tile stage across the seam).
-  auto stage_piece = [&](auto KIND, auto SLOT, auto NEXT, int kt, auto JJ) {
+  auto stage_piece = [&](auto KIND, auto SLOT, auto NEXT, int kt, auto JJ) __attribute__((always_inline)) {
     constexpr int kind = decltype(KIND)::value, slot = decltype(SLOT)::value, jj = decltype(JJ)::value;
     constexpr bool next = decltype(NEXT)::value != 0;
     const int soff = (EXP == 21 || EXP == 25) ? 0 : kt * TG_BKB;   // (ablation 21: always the first k-tile: L2 hits)
@@ -344,13 +344,13 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(pg_lds + slot * PG_SLOT + (wave + 8 * jj) * 64),
                                                16, vo, soff, 0, 0);
   };
-  auto stage = [&](auto KIND, auto SLOT, auto NEXT, int kt) {
+  auto stage = [&](auto KIND, auto SLOT, auto NEXT, int kt) __attribute__((always_inline)) {
     stage_piece(KIND, SLOT, NEXT, kt, std::integral_constant<int, 0>{});
     stage_piece(KIND, SLOT, NEXT, kt, std::integral_constant<int, 1>{});
   };
   // side data of tile `t` into copy `par`: every wave issues the same instructions (waves 4-7
   // repeat waves 0-3: same bytes to the same place), 256 bytes each
-  auto stage_side = [&](const PgTile& t, int par) {
+  auto stage_side = [&](const PgTile& t, int par) __attribute__((always_inline)) {
     const int col = (wave & 3) * 64 + lane;
     char* side = (char*)pg_lds;
     if constexpr (FUSE) {
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
   }
   // one quadrant: rows 64 i .. 64 i + 63, queries 32 j .. 32 j + 31 of the wave tile
   // s0 / s1: the phase's two LDS-DMA pieces when they are issued BETWEEN the MFMAs (kDmaInMma)
-  auto mma = [&](auto I, auto J, const u32x4 (&fb)[2][2], auto&& s0, auto&& s1) {
+  auto mma = [&](auto I, auto J, const u32x4 (&fb)[2][2], auto&& s0, auto&& s1) __attribute__((always_inline)) {
     constexpr int i = decltype(I)::value, j = decltype(J)::value;
     if constexpr (EB == 2) {
 #pragma unroll
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
 #ifdef PG_TRACE
   bool tracing = false;
 #endif
-  auto ktile = [&](auto PAR, auto TAIL, int kt) {
+  auto ktile = [&](auto PAR, auto TAIL, int kt) __attribute__((always_inline)) {
     constexpr int par = decltype(PAR)::value, tail = decltype(TAIL)::value;
     constexpr int mine = 4 * par, other = 4 * (par ^ 1);
     // half-tile staged in phase 0 is of k-tile kt + 1, in phases 1-3 of k-tile kt + 2
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
   //  tile -- a handful of ALU instructions -- instead of being computed once, kept live across the k loop and,
   //  the register file being full there, spilled: every reload of a spilled VGPR waits vmcnt(0), i.e. for the
   //  whole LDS-DMA ring)
-  auto flush_a = [&]() {
+  auto flush_a = [&]() __attribute__((always_inline)) {
     int tid = (int)threadIdx.x;
     asm volatile("" : "+v"(tid));
 #pragma unroll
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
       }
     }
   };
-  auto flush_b = [&](bool waited) {
+  auto flush_b = [&](bool waited) __attribute__((always_inline)) {
     if (!waited) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(fslot[0]), "+v"(fslot[1]) : "n"(PG_VMCNT) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" : "+v"(fslot[0]), "+v"(fslot[1])::"memory");
     int tid = (int)threadIdx.x;
@@ -523,7 +523,7 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
   };
 
   // ---- epilogue of one tile: scales (fp8), then scores out (materialised) or candidates parked
-  auto epilogue = [&](const PgTile& t, int par) {
+  auto epilogue = [&](const PgTile& t, int par) __attribute__((always_inline)) {
     const int wrow = wr * 128, wq = wc * 64;
     int lane_e = (int)threadIdx.x & 63;
     asm volatile("" : "+v"(lane_e));
@@ -538,10 +538,10 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
       // lands in scalar registers), one scalar test; only if some lane survives (a third of the
       // time at k = 100 over 1M rows) do those lanes compute their slot -- wave counter + rank inside
       // the mask -- and write (key, query) into the wave's eighth of the parking lot.  A wave that
-      // overfills its eighth gives the fused path up for the queries concerned: it raises their
-      // candidate counts past any capacity (a fire-and-forget atomic OR), select_final marks them,
-      // and the host re-runs them through the materialised path -- exact, just not fast (rows
-      // ordered by similarity to a query, or a query made of NaNs: every score survives).
+      // overfills its eighth sends the rest straight to the global candidate lists (below); only a
+      // query whose GLOBAL list overflows (32,768 candidates: rows ordered by similarity to it, or a
+      // query made of NaNs -- every score survives) is marked by select_final and re-run by the host
+      // through the materialised path.
       const int lr0 = wrow + 4 * g;                                        // the lane's first row inside the tile
       const int lim = (int)(n - t.row0 < PG_TILE ? n - t.row0 : PG_TILE);  // live rows of this tile
       if constexpr (EB == 1) {   // per-row and per-query dequantisation scales, applied in place (as tg_epilogue: v * (rs * qs))
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
       constexpr int WCAP = PG_PARK / 8;
       const unsigned kadr = PG_SIDE_KEY + (par * PG_PARK + wave * WCAP) * 8;
       int wcount = 0;   // wave-uniform
-      auto pass = [&](auto FULL, auto QALL) {
+      auto pass = [&](auto FULL, auto QALL) __attribute__((always_inline)) {
         constexpr bool full = decltype(FULL)::value, qall = decltype(QALL)::value;   // whole tile inside the corpus / the batch
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
@@ -602,7 +602,13 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
                   if (slot < WCAP) {   // (score bits, code): the order-preserving key is made at flush time
                     pg_lds_write_u64(kadr + slot * 8, ((uint64_t)(cbase + (uint32_t)(i * 16 + r)) << 32) | __builtin_bit_cast(uint32_t, v[r]));
                   } else {
-                    __hip_atomic_fetch_or(fstate_words + (int64_t)(t.q0 + ql) * fstate_stride, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // the wave's eighth is full: this candidate goes straight to the query's global list (a
+                    // returning atomic and a store, and hipcc's vmcnt(0) behind the atomic drains the DMA
+                    // ring -- the price of a tile full of one query's neighbours, paid only there)
+                    uint32_t* hp = fstate_words + (int64_t)(t.q0 + ql) * fstate_stride;
+                    const uint32_t gs = __hip_atomic_fetch_add(hp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (gs < fcap)
+                      fcand[(int64_t)(t.q0 + ql) * fcap + gs] = ((uint64_t)score_key(v[r]) << 32) | (uint32_t)(t.row0 + lr0 + i * 16 + r);
                   }
                 }
                 wcount += __builtin_popcountll(mask[r]);
@@ -619,7 +625,7 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
       // slots in the wave's eighth, (3) a second sweep parks them: v_cmpx makes the survivors the
       // active lanes, they store (score, code) and step their address, exec is restored -- five
       // instructions per register, the same whatever survives.
-      auto sweep = [&]() {
+      auto sweep = [&]() __attribute__((always_inline)) {
         float thr[NT];
         uint32_t base[NT];
 #pragma unroll
@@ -646,14 +652,10 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
         x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
         const int total = __builtin_amdgcn_readlane((int)x, 63);
         if (__builtin_expect(total > WCAP, 0)) {
-          // more than the wave's eighth holds: give the fused path up for the queries concerned
-          // (every query this lane has a survivor for, conservatively all four of its columns)
-          if (cnt != 0) {
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-              __hip_atomic_fetch_or(fstate_words + (int64_t)(t.q0 + wq + j * 16 + r16) * fstate_stride, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-          wcount = 0;
+          // more than the wave's eighth holds (rows ordered by topic: a tile full of one query's neighbours):
+          // the register-by-register path parks what fits and gives the fused path up for exactly the
+          // queries whose candidates did not
+          pass(std::true_type{}, std::true_type{});
         } else {
           wcount = total;
           if (total != 0) {

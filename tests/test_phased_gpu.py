@@ -60,3 +60,64 @@ def test_phased_odd_ktile_count_falls_back(gpu):
         exp = oracle.cpu_search(md, qd, 20)
         assert_topk_parity(s[qi], r[qi], [x for x, _ in exp], [i for _, i in exp], oracle.cpu_scores_f64(md, qd), label="odd k-tiles")
     idx.release()
+
+
+@pytest.mark.parametrize("dtype", ["f16", "fp8"])
+def test_phased_clustered_rows_overflow_the_parking_lot(gpu, dtype):
+    """A corpus ordered by topic: 300 consecutive rows are near-copies of one query (and 150 of
+    another), so single waves of the fused epilogue see more survivors than their eighth of the
+    parking lot holds (128).  The rest goes straight to the queries' global candidate lists; results
+    must be the oracle's and, bit for bit, the round-1 kernel's."""
+    from svs_amd import DeviceIndex
+    n, d, nq, k = 150000, 512 if dtype == "f16" else 1024, 200, 100
+    m, qs = corpus_and_query("gaussian", 4321, n, d, nq)
+    rng = np.random.default_rng(9)
+    for base, cnt, qi in ((70000, 300, 5), (70400, 150, 6), (20, 200, 150)):
+        noise = rng.standard_normal((cnt, d)).astype(np.float32) * np.float32(0.15 / np.sqrt(d))
+        rows = qs[qi][None, :] + noise
+        m[base:base + cnt] = rows / np.linalg.norm(rows, axis=1, keepdims=True)
+    idx = DeviceIndex(m, dtype=dtype)
+    s0, r0 = idx.search_batch(qs, k)
+    idx.set_variant(2)
+    s2, r2 = idx.search_batch(qs, k)
+    idx.set_variant(0)
+    # nobody leaves the fused path: what does not fit a wave's eighth goes straight to the global lists
+    assert np.array_equal(r0, r2) and np.array_equal(s0, s2)
+    left = []
+    md = idx.stored_rows()
+    for qi in sorted(set(left) | {5, 6, 150, 0, 199}):
+        qd = idx.stored_query(qs[qi])
+        exp = oracle.cpu_search(md, qd, k)
+        assert_topk_parity(s0[qi], r0[qi], [s for s, _ in exp], [i for _, i in exp],
+                           oracle.cpu_scores_f64(md, qd), label=f"clustered {dtype} q{qi}")
+    assert set(r0[5]) <= set(range(70000, 70300)) and set(r0[150]) <= set(range(20, 220))
+    idx.release()
+
+
+def test_phased_kernel_rate_floor(gpu):
+    """A tripwire, not a benchmark: the fused f16 panel kernel must run above 500 TFLOP/s (it measures
+    ~1,250).  hipcc has twice turned a small source change into accumulators kept in scratch memory or
+    hundreds of spilled registers -- correct results, 20x slower -- and parity tests cannot see that."""
+    import torch
+    from svs_amd import DeviceIndex
+    n, d, nq = 262144, 1536, 1024
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    m = torch.randn((n, d), device=dev, generator=g)
+    m /= m.norm(dim=1, keepdim=True)
+    idx = DeviceIndex.from_device_pointer(m.data_ptr(), n, d, device=0, dtype="f16")
+    del m
+    q = torch.randn((nq, d), device=dev, generator=g)
+    q = (q / q.norm(dim=1, keepdim=True)).cpu().numpy()
+    for _ in range(3):
+        idx.search_batch(q, 100)
+    idx.set_timing(True)
+    for _ in range(6):
+        idx.search_batch(q, 100)
+    _, _, cnt = idx.get_timing()
+    ms = idx.last_dominant_ms_sum / cnt
+    idx.release()
+    tflops = 2.0 * n * d * nq / (ms * 1e-3) / 1e12
+    print(f"phased f16 kernel: {ms:.3f} ms, {tflops:.0f} TFLOP/s")
+    assert tflops > 500, f"{tflops:.0f} TFLOP/s: look at the kernel's register / scratch statistics"
