@@ -70,7 +70,11 @@ constexpr int PG_THREADS = 512;
 #ifndef PG_DMA_AT1
 #define PG_DMA_AT1 1
 #endif
+#ifdef PG_VMCNT_FORCE   // (tools: DMA-only ablations with more pieces in flight than the ring allows -- results are wrong)
+#define PG_VMCNT PG_VMCNT_FORCE
+#else
 #define PG_VMCNT (kDmaInMma ? 8 : 10)
+#endif
 
 #ifdef PG_CLOCKS   // tools/gemm_phased_bench.hip only: shader cycles and 100 MHz ticks a workgroup spent in the kernel
 __device__ unsigned long long* pg_clock_buf;

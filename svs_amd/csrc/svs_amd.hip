@@ -1532,8 +1532,13 @@ int32_t svs_index_search(svs_index* idx, const float* queries, int32_t nq, int32
     HIP_TRY(hipHostMalloc((void**)&c->out_r_pin, on * sizeof(int64_t), hipHostMallocDefault));
     c->out_pin_cap = on;
   }
-  memcpy(c->q_pin, queries, qn * sizeof(float));
-  HIP_TRY(hipMemcpyAsync(c->q_dev, c->q_pin, qn * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  // queries -> pinned staging -> HBM, in 1 MiB pieces: the DMA of piece i runs under the host copy of
+  // piece i + 1 (a 1024 x 1536 batch is 6.3 MB: ~0.5 ms of memcpy + ~0.13 ms of PCIe back to back)
+  for (size_t off = 0; off < qn; off += (size_t)262144) {
+    const size_t len = std::min((size_t)262144, qn - off);
+    memcpy(c->q_pin + off, queries + off, len * sizeof(float));
+    HIP_TRY(hipMemcpyAsync(c->q_dev + off, c->q_pin + off, len * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  }
   // The final top-k kernel stores its k results straight into the pinned host
   // buffers (device-visible, zero-copy): no D2H copies on the latency path.
   if ((rc = enqueue_search(idx, c, c->q_dev, nq, count, count, c->out_s_pin, c->out_r_pin, c->stream, true)) != SVS_OK) {
