@@ -268,7 +268,7 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
     const uint8_t* __restrict__ M, const uint8_t* __restrict__ Q, float* __restrict__ scores,
     int64_t n, int ldb, int64_t sstride, int nq, int gx, int gy, uint32_t* __restrict__ fstate_words, int fstate_stride,
     uint64_t* __restrict__ fcand, uint32_t fcap, const float* __restrict__ fthr, int fthr_stride,
-    const float* __restrict__ rscale, const float* __restrict__ qscale) {
+    const float* __restrict__ rscale, const float* __restrict__ qscale, const TgPairs pairs = TgPairs{}) {
   static_assert(EB == 1 || EB == 2, "f16 or fp8 operands");
   extern __shared__ u32x4 pg_lds[];
   PG_CLOCK_STAMP(0);
@@ -359,8 +359,9 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
     char* side = (char*)pg_lds;
     if constexpr (FUSE) {
       const int live = nq - t.q0 < PG_TILE ? nq - t.q0 : PG_TILE;
+      // (stride 0: one threshold for every query -- pair mode -- is one 4-byte record read by every lane)
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(fthr + (int64_t)t.q0 * fthr_stride), 0,
-                                                                          live * fthr_stride * 4, 0x00020000);
+                                                                          fthr_stride ? live * fthr_stride * 4 : 4, 0x00020000);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(side + PG_SIDE_THR + par * 1024 + (wave & 3) * 256),
                                                4, col * fthr_stride * 4, 0, 0, 0);
     }
@@ -521,7 +522,7 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
         const uint64_t sc = pg_lds_read_u64(PG_SIDE_KEY + (f_pp * PG_PARK + e) * 8);   // (score bits, code)
         const uint32_t code = (uint32_t)(sc >> 32);
         fcand[(int64_t)(f_q0 + (int)(code >> 8)) * fcap + fslot[r]] =
-            ((uint64_t)score_key(__builtin_bit_cast(float, (uint32_t)sc)) << 32) | (uint32_t)(f_row0 + (code & 255u));
+            ((uint64_t)score_key(__builtin_bit_cast(float, (uint32_t)sc)) << 32) | (uint32_t)(pairs.row_base + f_row0 + (code & 255u));
       }
     }
   };
@@ -577,7 +578,19 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
         for (int j = 0; j < NT; ++j) {
           const int ql = wq + j * 16 + r16;
           const float thr = pg_lds_read_f32(PG_SIDE_THR + par * 1024 + ql * 4);
-          const unsigned long long qokm = __ballot(t.q0 + ql < nq);
+          // pair mode (svs_index_top_pairs, TgPairs in gemm_tiled.h): the queries ARE corpus rows; a score counts only
+          // for a row above the query's own, and only for queries this chunk is responsible for
+          // (32-bit and tile-local: rows of this tile count from local row plo + 1 on; opaque, or hipcc forms all 128
+          //  64-bit comparisons of a lane ahead of time and spills them)
+          int plo = -1;
+          bool mine = true;
+          if (pairs.on) {
+            const long long qrow = pairs.query_row0 + t.q0 + ql, dlt = qrow - (pairs.row_base + t.row0);
+            plo = dlt < -1 ? -1 : (dlt > PG_TILE ? PG_TILE : (int)dlt);
+            mine = qrow >= pairs.first_query;
+          }
+          asm volatile("" : "+v"(plo));
+          const unsigned long long qokm = __ballot(t.q0 + ql < nq && mine);
           // (opaque: the 128 codes of a lane do not depend on the tile, and hipcc otherwise computes them all at
           //  kernel entry and spills them -- ~500 registers' worth of scratch traffic behind vmcnt(0) waits)
           uint32_t cbase = (uint32_t)(lr0 | (ql << 8));
@@ -594,7 +607,8 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
               // lanes whose score is not below the threshold (unordered-or-greater-equal: a NaN passes)
               mask[r] = __builtin_amdgcn_fcmpf(v[r], thr, 11 /* FCMP_UGE */);
               if constexpr (!qall) mask[r] &= qokm;
-              if constexpr (!full) mask[r] &= __ballot(lr0 + i * 16 + r < lim);
+              if constexpr (!full)
+                mask[r] &= __ballot(lr0 + i * 16 + r < lim && lr0 + i * 16 + r > plo);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -612,7 +626,7 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
                     uint32_t* hp = fstate_words + (int64_t)(t.q0 + ql) * fstate_stride;
                     const uint32_t gs = __hip_atomic_fetch_add(hp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (gs < fcap)
-                      fcand[(int64_t)(t.q0 + ql) * fcap + gs] = ((uint64_t)score_key(v[r]) << 32) | (uint32_t)(t.row0 + lr0 + i * 16 + r);
+                      fcand[(int64_t)(t.q0 + ql) * fcap + gs] = ((uint64_t)score_key(v[r]) << 32) | (uint32_t)(pairs.row_base + t.row0 + lr0 + i * 16 + r);
                   }
                 }
                 wcount += __builtin_popcountll(mask[r]);
@@ -677,7 +691,13 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
           }
         }
       };
-      if (lim == PG_TILE && t.q0 + PG_TILE <= nq && EXP != 31) sweep();
+      // pair mode: tiles wholly above the diagonal are ordinary tiles, tiles wholly on or below it hold nothing,
+      // the few that straddle it (or hold queries of the previous chunk) take the masked path
+      const long long prow0 = pairs.row_base + t.row0, pq0 = pairs.query_row0 + t.q0;
+      const bool pair_plain = !pairs.on || (prow0 > pq0 + PG_TILE - 1 && pq0 >= pairs.first_query);
+      const bool pair_empty = pairs.on && prow0 + PG_TILE - 1 <= pq0;
+      if (pair_empty) wcount = 0;
+      else if (lim == PG_TILE && t.q0 + PG_TILE <= nq && pair_plain && EXP != 31) sweep();
       else pass(std::false_type{}, std::false_type{});   // (EXP 31: the branchy path everywhere, A/B)
       if (lane == 0) pg_lds_write_u32(PG_SIDE_CNT + (par * 8 + wave) * 4, (uint32_t)(wcount < WCAP ? wcount : WCAP));
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // parked entries written before this wave's next barrier

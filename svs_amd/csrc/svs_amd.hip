@@ -621,10 +621,12 @@ int launch_phased(const svs_index* idx, Ctx* c, int64_t n_rows, int nq, float* s
   const int64_t total = (int64_t)gx * gy;
   const unsigned grid = (unsigned)std::min<int64_t>(total, idx->cu_count);   // one persistent workgroup per CU
   const uint8_t* Q = EB == 2 ? (const uint8_t*)c->qh : (const uint8_t*)c->q8;
+  // pair mode: the row operand starts at global row fl.pairs.row_base (n_rows counts from there)
+  const int64_t rb = fl.pairs.on ? fl.pairs.row_base : 0;
   hipLaunchKernelGGL((gemm_phased_kernel<FUSE, EB, EXP>), dim3(grid), dim3(PG_THREADS), PG_LDS_TOTAL, st,
-                     (const uint8_t*)idx->rows, Q, scores, n_rows, (int)(idx->ld * EB), sstride, nq, gx, gy,
+                     (const uint8_t*)idx->rows + (size_t)rb * idx->ld * EB, Q, scores, n_rows, (int)(idx->ld * EB), sstride, nq, gx, gy,
                      fl.state, (int)SCR_WORDS, fl.cand, (uint32_t)CAND_CAP, fl.thr, fl.thr_stride,
-                     (const float*)idx->row_scales, (const float*)c->q8s);
+                     (const float*)(idx->row_scales ? idx->row_scales + rb : nullptr), (const float*)c->q8s, fl.pairs);
   return SVS_OK;
 }
 
@@ -641,7 +643,7 @@ int launch_tiled_eb(const svs_index* idx, Ctx* c, int64_t n_rows, int nq, int bn
                     FuseLaunch fl, hipStream_t st) {
   const bool f = fl.state != nullptr;
   if constexpr (EB != 4) {
-    if (bn == 256 && !fl.pairs.on && phased_ok(idx, n_rows, nq)) {
+    if (bn == 256 && phased_ok(idx, n_rows, nq)) {
       if (f && idx->variant.load() == 8)   // A/B: LDS-DMA pieces issued with the fragment reads
         return launch_phased<true, EB, 30>(idx, c, n_rows, nq, scores, sstride, fl, st);
       if (f && idx->variant.load() == 9)   // A/B: fused epilogue with a branch per register

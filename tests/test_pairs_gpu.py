@@ -78,7 +78,8 @@ def test_top_pairs_ties_and_edges(gpu):
 
 # ---- corpora past n^2 = 2^32 scores: tiled pair-mode GEMM (svs_amd.hip top_pairs_tiled) ----------
 @pytest.mark.parametrize("n,d,k,dtype", [(5000, 256, 300, "f32"), (20000, 512, 1000, "f16"), (20000, 256, 200, "fp8"),
-                                         (3001, 128, 5000, "f16"), (9000, 1536, 100, "f16"), (1100, 64, 50, "f32")])
+                                         (3001, 128, 5000, "f16"), (9000, 1536, 100, "f16"), (1100, 64, 50, "f32"),
+                                         (12000, 1024, 400, "fp8")])
 def test_tiled_pairs_equal_materialised(gpu, n, d, k, dtype):
     """variant 1 forces the large-corpus path on a corpus the materialised path can also do: the
     two must return the same pairs in the same order with the same scores (same MFMA kernels, the
@@ -121,7 +122,7 @@ def _cpu_top_pairs_chunked(md, k, chunk=2000):
     return best
 
 
-@pytest.mark.parametrize("n,d,k,dtype", [(120_000, 128, 200, "f32"), (150_000, 256, 500, "f16")])
+@pytest.mark.parametrize("n,d,k,dtype", [(120_000, 128, 200, "f32"), (150_000, 256, 500, "f16"), (70_000, 768, 300, "f16")])   # (the last: phased kernel in pair mode)
 def test_top_pairs_large_corpus(gpu, n, d, k, dtype):
     """n >= 100k (n^2 > 2^32: nothing the size of the score matrix exists anywhere).  Planted
     near-duplicates must come out on top; the whole list against a chunked numpy restatement of
