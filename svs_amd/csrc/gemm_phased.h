@@ -654,12 +654,14 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
         }
         auto val = [&](int i, int j, int r) { return acc[i][j][r]; };
         uint32_t cnt = 0;
+        if constexpr (EXP != 33) {   // (EXP 33, timing only: no counting sweep -- what a single-sweep epilogue would save)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
           for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) cnt += !(val(i, j, r) < thr[j]) ? 1u : 0u;   // (a NaN passes)
+        }
         // inclusive scan over the wave: four row shifts, then the two row broadcasts
         uint32_t x = cnt;
         x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);
@@ -668,7 +670,8 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
         x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);
         x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
         x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
-        const int total = __builtin_amdgcn_readlane((int)x, 63);
+        int total = __builtin_amdgcn_readlane((int)x, 63);
+        if constexpr (EXP == 33) { total = 64; x = (uint32_t)(lane & 15); cnt = 0; }
         if (__builtin_expect(total > WCAP, 0)) {
           // more than the wave's eighth holds (rows ordered by topic: a tile full of one query's neighbours):
           // the register-by-register path parks what fits and gives the fused path up for exactly the
