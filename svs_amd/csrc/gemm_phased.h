@@ -158,6 +158,16 @@ __device__ __forceinline__ void pg_park_if(unsigned& ak, float v, float thr, uin
       : "vcc", "memory");
 }
 
+// LDS byte address of a piece's destination = the wave's base + a literal, formed where it is used: the sixteen
+// destinations of a wave are loop invariants, and hoisted they cost sixteen scalar registers the kernel does
+// not have (-> v_readlane restores of spilled SGPRs inside the k loop)
+template <int IMM>
+__device__ __forceinline__ unsigned pg_lds_dest(unsigned wave_base) {
+  unsigned a;
+  asm volatile("s_add_u32 %0, %1, %2" : "=s"(a) : "s"(wave_base), "n"(IMM) : "scc");
+  return a;
+}
+
 __device__ __forceinline__ int pg_voff(int vbase, int uniform_bytes) {
   int vo;
   asm volatile("v_add_u32_e32 %0, %1, %2" : "=v"(vo) : "s"(uniform_bytes), "v"(vbase));
@@ -291,6 +301,7 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
   // (the swizzle depends on bits 1-3 of li only).  The row part must stay in the VECTOR offset -- the descriptor's
   // range check does not see soffset -- so each piece adds its scalar to the base just before it is issued
   // (pg_voff: one v_add, volatile so that hipcc does not hoist the eight sums back into eight live registers).
+  const unsigned wave_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)pg_lds + (unsigned)wave * 1024u;   // LDS byte address of the wave's 1 KiB in slot 0
   int vbase;
   {
     const int li0 = 8 * wave + (lane >> 3), pc = lane & 7;
@@ -341,12 +352,11 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
     const __amdgpu_buffer_rsrc_t rs = (kind & 1) ? (next ? nxt.a : cur.a) : (next ? nxt.b : cur.b);
     const int rows = (kind & 1) ? jj * 128 + (kind >> 1) * 64 : wr * 32 + jj * 128 + (kind >> 1) * 32;
     const int vo = pg_voff(vbase, rows * ldb);
+    const unsigned dst = pg_lds_dest<slot * PG_SLOT * 16 + jj * 8192>(wave_lds);
     if constexpr (EXP == 20 && (kind & 1))   // (ablation: corpus rows nontemporal)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(pg_lds + slot * PG_SLOT + (wave + 8 * jj) * 64),
-                                               16, vo, soff, 0, 2);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(uintptr_t)dst, 16, vo, soff, 0, 2);
     else
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(pg_lds + slot * PG_SLOT + (wave + 8 * jj) * 64),
-                                               16, vo, soff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(uintptr_t)dst, 16, vo, soff, 0, 0);
   };
   auto stage = [&](auto KIND, auto SLOT, auto NEXT, int kt) __attribute__((always_inline)) {
     stage_piece(KIND, SLOT, NEXT, kt, std::integral_constant<int, 0>{});
@@ -654,7 +664,7 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
         }
         auto val = [&](int i, int j, int r) { return acc[i][j][r]; };
         uint32_t cnt = 0;
-        if constexpr (EXP != 33) {   // (EXP 33, timing only: no counting sweep -- what a single-sweep epilogue would save)
+        {
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -671,7 +681,6 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
         x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
         x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
         int total = __builtin_amdgcn_readlane((int)x, 63);
-        if constexpr (EXP == 33) { total = 64; x = (uint32_t)(lane & 15); cnt = 0; }
         if (__builtin_expect(total > WCAP, 0)) {
           // more than the wave's eighth holds (rows ordered by topic: a tile full of one query's neighbours):
           // the register-by-register path parks what fits and gives the fused path up for exactly the
