@@ -265,6 +265,22 @@ __device__ __forceinline__ void emit_topk(const uint64_t* S, int count, int k, i
 }
 
 // One workgroup: exact k-th largest of the M unique 64-bit keys key_at(0..M),
+// Histogram increment with the wave's dominant bin aggregated: candidate keys of one query share their
+// leading bits, so in the upper radix passes (and for the bulk of a prefix's scores) most lanes of a wave hit
+// ONE bin -- 64 LDS atomics on one address are served one after the other.  The lanes that share the first
+// active lane's bin are counted with a ballot and added by that lane alone; the rest add for themselves.
+// Must be called by all lanes of the wave (valid == false: nothing to add).
+__device__ __forceinline__ void hist_add_wave(uint32_t* lh, bool valid, uint32_t bin) {
+  const unsigned long long act = __ballot(valid);
+  if (act == 0) return;
+  const int first = __builtin_ctzll(act);
+  const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)bin, first);
+  const unsigned long long same = __ballot(valid && bin == b0);
+  const int lane = (int)(threadIdx.x & 63);
+  if (lane == first) atomicAdd(&lh[b0], (uint32_t)__builtin_popcountll(same));
+  else if (valid && bin != b0) atomicAdd(&lh[bin], 1u);
+}
+
 // MSB-first radix select with an LDS histogram (11 bits per pass, early exit
 // as soon as a whole bucket is taken).  Returns T such that exactly k keys
 // satisfy key >= T.  lh: RS_BINS words, sh: 256+2 words of LDS.
@@ -319,7 +335,7 @@ __device__ __forceinline__ uint64_t block_radix_select_regs(const uint64_t (&kr)
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < NPT; ++j)
-      if (j < mine && (kr[j] & pmask) == prefix) atomicAdd(&lh[(uint32_t)(kr[j] >> shift) & (RS_BINS - 1)], 1u);
+      hist_add_wave(lh, j < mine && (kr[j] & pmask) == prefix, (uint32_t)(kr[j] >> shift) & (RS_BINS - 1));
     __syncthreads();
     uint32_t b, k2;
     pick_bucket<256>(lh, RS_BINS, k_rem, sh, &b, &k2);
@@ -334,7 +350,7 @@ __device__ __forceinline__ uint64_t block_radix_select_regs(const uint64_t (&kr)
       __syncthreads();
 #pragma unroll
       for (int j = 0; j < NPT; ++j)
-        if (j < mine && (kr[j] & pmask) == prefix) atomicAdd(&lh[(uint32_t)kr[j] & 511u], 1u);
+        hist_add_wave(lh, j < mine && (kr[j] & pmask) == prefix, (uint32_t)kr[j] & 511u);
       __syncthreads();
       pick_bucket<256>(lh, RS_BINS, k_rem, sh, &b, &k2);
       return prefix | b;
@@ -459,6 +475,44 @@ __global__ __launch_bounds__(FINAL_THREADS) void prefix_kth_kernel(
   const float* s = scores + (int64_t)blockIdx.x * score_stride;
   uint32_t prefix = 0, pmask = 0, k_rem = (uint32_t)k;
   const int shifts[3] = {21, 10, 0};
+  constexpr int PK_REGS = 64;   // score keys per thread held in registers: prefixes of up to 16,384 rows are read ONCE
+  if (n <= (int64_t)FINAL_THREADS * PK_REGS && (score_stride & 3) == 0 && (((uintptr_t)scores) & 15) == 0) {
+    // (three passes over the score vector in L2 were what this kernel cost: 200 MB for 1024 queries)
+    uint32_t kr[PK_REGS];
+#pragma unroll
+    for (int j = 0; j < PK_REGS / 4; ++j) {
+      const int64_t i = ((int64_t)j * FINAL_THREADS + threadIdx.x) * 4;
+      f32x4_sel q4 = {0.f, 0.f, 0.f, 0.f};
+      if (i + 3 < n) q4 = *(const f32x4_sel*)(s + i);
+      else {
+        if (i < n) q4.x = s[i];
+        if (i + 1 < n) q4.y = s[i + 1];
+        if (i + 2 < n) q4.z = s[i + 2];
+      }
+      // key 0 (below every real score's key) marks "no element"
+      kr[4 * j] = i < n ? score_key(q4.x) : 0u;
+      kr[4 * j + 1] = i + 1 < n ? score_key(q4.y) : 0u;
+      kr[4 * j + 2] = i + 2 < n ? score_key(q4.z) : 0u;
+      kr[4 * j + 3] = i + 3 < n ? score_key(q4.w) : 0u;
+    }
+    for (int pass = 0; pass < 3; ++pass) {
+      const int shift = shifts[pass];
+      const uint32_t bins = pass == 2 ? 1024u : (uint32_t)RS_BINS;
+      for (int i = threadIdx.x; i < RS_BINS; i += blockDim.x) lh[i] = 0;
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < PK_REGS; ++j)
+        if (kr[j] != 0u && (kr[j] & pmask) == prefix) atomicAdd(&lh[(kr[j] >> shift) & (bins - 1)], 1u);
+      __syncthreads();
+      uint32_t b, k2;
+      pick_bucket<256>(lh, (int)bins, k_rem, sh, &b, &k2);
+      prefix |= b << shift;
+      pmask |= (bins - 1) << shift;
+      k_rem = k2;
+    }
+    if (threadIdx.x == 0) thr[blockIdx.x] = key_score(prefix);
+    return;
+  }
   for (int pass = 0; pass < 3; ++pass) {
     const int shift = shifts[pass];
     const uint32_t bins = pass == 2 ? 1024u : (uint32_t)RS_BINS;
