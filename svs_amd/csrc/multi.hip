@@ -208,7 +208,7 @@ int32_t svs_multi_search(svs_multi* m, const float* queries, int32_t nq, int32_t
   if (nq == 0 || count == 0) return SVS_OK;
   if (!out_scores || !out_rows) return refail(SVS_ERR_INVALID, "null output");
   const int L = (int)live.size();
-  struct Part { std::vector<float> s; std::vector<int64_t> r; int32_t cnt = 0; int rc = SVS_OK; std::string msg; };
+  struct Part { std::vector<float> s; std::vector<int64_t> r; int32_t cnt = 0; int stride = 0; int rc = SVS_OK; std::string msg; };
   // (shared: the last worker is still inside done() when the caller wakes up and returns)
   auto latch = std::make_shared<Latch>(L);
   auto parts = std::make_shared<std::vector<Part>>((size_t)L);
@@ -216,13 +216,23 @@ int32_t svs_multi_search(svs_multi* m, const float* queries, int32_t nq, int32_t
   for (int t = 0; t < L; ++t) {
     const int g = live[t];
     Part* p = &part[t];
-    // (svs_index_search's rows are k apart, whatever the shard's count is: include/svs_amd.h)
-    p->s.resize((size_t)nq * (size_t)kk);
-    p->r.resize((size_t)nq * (size_t)kk);
+    // every shard is asked for min(k, its live rows): svs_index_search's output rows are k apart
+    // (include/svs_amd.h), so that is also the stride of its part -- never nq * k for an absurd k
+    const int kg = (int)std::min<int64_t>(kk, info[g].n - info[g].n_masked);
+    p->stride = kg;
+    try {
+      p->s.resize((size_t)nq * (size_t)kg);
+      p->r.resize((size_t)nq * (size_t)kg);
+    } catch (const std::bad_alloc&) {
+      // (jobs already posted hold `parts` alive and finish on their own)
+      for (int u = t; u < L; ++u) latch->done();
+      latch->wait();
+      return refail(SVS_ERR_NOMEM, "out of host memory for the shard results");
+    }
     svs_index* shard = m->shards[g];
     m->workers[g]->post([=] {
       (void)parts;   // keeps the result buffers alive as long as a job can touch them
-      p->rc = svs_index_search(shard, queries, nq, d, k, p->s.data(), p->r.data(), &p->cnt);
+      p->rc = svs_index_search(shard, queries, nq, d, kg, p->s.data(), p->r.data(), &p->cnt);
       if (p->rc != SVS_OK) p->msg = svs_last_error();
       latch->done();
     });
@@ -240,13 +250,13 @@ int32_t svs_multi_search(svs_multi* m, const float* queries, int32_t nq, int32_t
       int64_t brow = 0;
       for (int t = 0; t < L; ++t) {
         if (head[t] >= part[t].cnt) continue;
-        const size_t at = (size_t)qi * (size_t)kk + (size_t)head[t];
+        const size_t at = (size_t)qi * (size_t)part[t].stride + (size_t)head[t];
         const uint32_t key = svs::score_key(part[t].s[at]);
         const int64_t row = part[t].r[at];
         if (best < 0 || key > bkey || (key == bkey && row > brow)) { best = t; bkey = key; brow = row; }
       }
       if (best < 0) return refail(SVS_ERR_DEVICE, "internal: shards returned fewer rows than they hold");
-      const size_t at = (size_t)qi * (size_t)kk + (size_t)head[best]++;
+      const size_t at = (size_t)qi * (size_t)part[best].stride + (size_t)head[best]++;
       out_scores[(size_t)qi * kk + o] = part[best].s[at];
       out_rows[(size_t)qi * kk + o] = part[best].r[at];
     }
