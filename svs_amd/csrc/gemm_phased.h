@@ -353,7 +353,7 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
     const int rows = (kind & 1) ? jj * 128 + (kind >> 1) * 64 : wr * 32 + jj * 128 + (kind >> 1) * 32;
     const int vo = pg_voff(vbase, rows * ldb);
     const unsigned dst = pg_lds_dest<slot * PG_SLOT * 16 + jj * 8192>(wave_lds);
-    if constexpr (EXP == 20 && (kind & 1))   // (ablation: corpus rows nontemporal)
+    if constexpr (EXP == 20 && (kind & 1))   // (corpus rows nontemporal: the single-query-tile form, see launch_tiled_eb)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(uintptr_t)dst, 16, vo, soff, 0, 2);
     else
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(uintptr_t)dst, 16, vo, soff, 0, 0);

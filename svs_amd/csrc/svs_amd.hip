@@ -648,6 +648,11 @@ int launch_tiled_eb(const svs_index* idx, Ctx* c, int64_t n_rows, int nq, int bn
         return launch_phased<true, EB, 30>(idx, c, n_rows, nq, scores, sstride, fl, st);
       if (f && idx->variant.load() == 9)   // A/B: fused epilogue with a branch per register
         return launch_phased<true, EB, 31>(idx, c, n_rows, nq, scores, sstride, fl, st);
+      // One query tile (up to 256 queries): every corpus byte is used by exactly one workgroup, so its LDS-DMA
+      // pieces are issued nontemporal (EXP 20) and leave the L2 to the queries (configs[4]: 7.63 vs 7.89-8.0 ms in
+      // tools/gemm_phased_bench; with several query tiles the corpus tile is SHARED through the L2: not there).
+      if (f && nq <= PG_TILE && idx->variant.load() != 9)
+        return launch_phased<true, EB, 20>(idx, c, n_rows, nq, scores, sstride, fl, st);
       return f ? launch_phased<true, EB>(idx, c, n_rows, nq, scores, sstride, fl, st)
                : launch_phased<false, EB>(idx, c, n_rows, nq, scores, sstride, fl, st);
     }
