@@ -106,3 +106,20 @@ def test_c_caller_release_races_with_search(gpu, tmp_path):
     exe = _build_c(tmp_path, "release_race")
     out = subprocess.run([str(exe), "12"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.startswith("ok"), (out.returncode, out.stdout, out.stderr)
+
+
+def test_c_multi_device_program_builds(tmp_path):
+    """CPU: tests/c/multi_device.c compiles (C99 header) and links against the ABI."""
+    import shutil
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    assert os.path.exists(_build_c(tmp_path, "multi_device"))
+
+
+@pytest.mark.gpu
+def test_c_caller_multi_device(gpu, tmp_path):
+    """A C caller of svs_multi_*: 2, 3 and 5 shards against one index (tests/c/multi_device.c)."""
+    import subprocess
+    exe = _build_c(tmp_path, "multi_device")
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.startswith("ok"), (out.returncode, out.stdout, out.stderr)
