@@ -549,13 +549,14 @@ class AsyncKB:
             db = await self._ensure_db()
             await self.embeddings_matrix.get(db)
             # own a reference now: a later invalidate() must not affect this search
-            idx, lookup = self.embeddings_matrix.hold()
+            idx, lookup, co = self.embeddings_matrix.hold_search()
         try:
             query_vec = np.array((await self._embed([query]))[0], dtype=np.float32)
             _LOG.info("got embedding for query!")
 
             def superheavy() -> List[Tuple[float, int]]:
-                res = idx.search(query_vec, n)
+                # tasks whose searches are in flight together share corpus passes (svs_amd/coalesce.py)
+                res = co.search(idx, query_vec, n) if co is not None else idx.search(query_vec, n)
                 return [(score, int(lookup.arr[row])) for score, row in res]
 
             emb_ids = await loop.run_in_executor(None, superheavy)

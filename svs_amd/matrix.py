@@ -26,6 +26,7 @@ from typing import Any, Callable, List, Optional, Tuple
 
 import numpy as np
 
+from .coalesce import SearchCoalescer
 from .index import DeviceIndex
 
 _LOG = logging.getLogger(__name__)
@@ -74,6 +75,9 @@ class DeviceEmbeddingsMatrix:
         self.embeddings_matrix: Optional[np.ndarray] = None   # host copy (pairwise path), optional
         self._lookup: Optional[_Lookup] = None
         self._n_dead = 0
+        # concurrent single-query searches of one index generation share corpus passes (coalesce.py)
+        self.coalesce = True
+        self._coalescer: Optional[SearchCoalescer] = None
 
     @property
     def emb_id_lookup(self) -> Optional[np.ndarray]:
@@ -90,6 +94,7 @@ class DeviceEmbeddingsMatrix:
             self.embeddings_matrix = None
             self._lookup = None
             self._n_dead = 0
+            self._coalescer = None
         if idx is not None:
             idx.release()
 
@@ -239,9 +244,10 @@ class DeviceEmbeddingsMatrix:
     # -- the superheavy() body ---------------------------------------------
     def search(self, query_vec: np.ndarray, n: int) -> List[Tuple[float, int]]:
         """``superheavy()`` (src/svs/kb.py:1622-1627): [(score, emb_id)]."""
-        idx, lookup = self.hold()
+        idx, lookup, co = self.hold_search()
         try:
-            res = idx.search(query_vec, n)
+            # concurrent callers (threads of a server, AsyncKB's executor threads) share corpus passes
+            res = co.search(idx, query_vec, n) if co is not None else idx.search(query_vec, n)
             return [(score, int(lookup.arr[row])) for score, row in res]
         finally:
             idx.release()
@@ -276,6 +282,17 @@ class DeviceEmbeddingsMatrix:
             if idx is None or lookup is None:
                 raise RuntimeError("embeddings matrix is not loaded (call get_sync/get first)")
             return idx.share(), lookup
+
+    def hold_search(self) -> Tuple[Any, _Lookup, Optional[SearchCoalescer]]:
+        """``hold()`` plus the generation's coalescer (None when switched off): what ``retrieve``
+        uses for its single-query search."""
+        with self._mu:
+            idx, lookup = self.index, self._lookup
+            if idx is None or lookup is None:
+                raise RuntimeError("embeddings matrix is not loaded (call get_sync/get first)")
+            if self.coalesce and self._coalescer is None:
+                self._coalescer = SearchCoalescer()
+            return idx.share(), lookup, (self._coalescer if self.coalesce else None)
 
 
 # --------------------------------------------------------------------------
