@@ -167,6 +167,16 @@ int32_t svs_index_info(const svs_index* idx, svs_index_info_t* out);
 int32_t svs_index_search(svs_index* idx, const float* queries, int32_t nq, int32_t d, int32_t k,
                          float* out_scores, int64_t* out_rows, int32_t* out_count);
 
+/* Coalescing of concurrent single-query searches (off by default).  AsyncKB.retrieve runs its np.dot on
+ * an executor thread outside the KB lock (src/svs/kb.py:1184-1190), so a server has many threads inside the
+ * search at once; with enable != 0, svs_index_search calls with nq == 1 that arrive while the device is busy
+ * are queued and answered TOGETHER by one batched pass over the corpus when it is free (up to 256; a call that
+ * finds the device idle runs at once, alone).  Rows and their order are those of the solo search; scores can
+ * differ from the single-query kernels' in the last bits (another summation order).  Errors stay with the call
+ * that made them.  svs_index_coalesce_stats: passes made / queries answered through this path. */
+int32_t svs_index_set_coalesce(svs_index* idx, int32_t enable);
+int32_t svs_index_coalesce_stats(svs_index* idx, int64_t* passes, int64_t* queries);
+
 /* Device-resident variant for pipelines and the multi-GPU gather (8(e)): queries
  * and outputs are device pointers on the index's device, work is enqueued on
  * `hip_stream` (a hipStream_t; NULL = the default stream) and the call returns

@@ -22,6 +22,15 @@ from typing import Any, List, Optional, Tuple
 import numpy as np
 
 
+def _as_list(res) -> List[Tuple[float, int]]:
+    """(scores f32, rows i64) -> [(float, int)] as ``DeviceIndex.search`` returns it (float(np.float32) is the
+    exact widening the reference's ``float(scores[i])`` does, src/svs/util.py:203)."""
+    if isinstance(res, list):
+        return res
+    s, r = res
+    return list(zip(s.astype(np.float64).tolist(), r.tolist()))
+
+
 class _Req:
     __slots__ = ("q", "n", "event", "lead", "result", "error")
 
@@ -29,7 +38,7 @@ class _Req:
         self.q, self.n = q, n
         self.event = threading.Event()
         self.lead = False
-        self.result: Optional[List[Tuple[float, int]]] = None
+        self.result: Any = None
         self.error: Optional[BaseException] = None
 
 
@@ -63,7 +72,7 @@ class SearchCoalescer:
             if not req.lead:                            # served by somebody else's pass
                 if req.error is not None:
                     raise req.error
-                return req.result
+                return _as_list(req.result)
         # this thread drives the device until its own request is answered, then hands over
         while True:
             with self._mu:
@@ -81,7 +90,7 @@ class SearchCoalescer:
                 self._busy = False
         if req.error is not None:
             raise req.error
-        return req.result
+        return _as_list(req.result)
 
     def _run(self, index: Any, batch: List[_Req]) -> None:
         try:
@@ -92,7 +101,8 @@ class SearchCoalescer:
                 s, rows = index.search_batch(np.stack([r.q for r in batch]), kmax)
                 for i, r in enumerate(batch):
                     c = min(r.n, s.shape[1])            # a top-k list's first n entries ARE the top-n list
-                    r.result = [(float(a), int(b)) for a, b in zip(s[i, :c], rows[i, :c])]
+                    r.result = (s[i, :c], rows[i, :c])  # (each caller turns its own row into Python objects:
+                                                        #  the thread that drives the device hands over first)
             self.batches += 1
             self.queries += len(batch)
         except BaseException as e:                      # noqa: BLE001 -- every waiter must be released

@@ -123,6 +123,22 @@ struct svs_index {
   std::mutex stg_mu;
   std::atomic<bool> staging_pending{false};
 
+  // svs_index_set_coalesce: single-query host searches that are in flight together share corpus passes
+  struct Waiter {
+    const float* q;
+    int k, count = 0, rc = SVS_OK;
+    float* out_s;
+    int64_t* out_r;
+    std::string err;
+    bool done = false, lead = false;
+    std::condition_variable cv;
+  };
+  std::atomic<bool> coalesce{false};
+  std::mutex co_mu;
+  std::vector<Waiter*> co_pending;
+  bool co_busy = false;
+  std::atomic<int64_t> co_passes{0}, co_queries{0};
+
   std::atomic<int> timing{0};          // 0 off, N: time every N-th search
   std::atomic<uint32_t> timing_seq{0};
   std::atomic<int> variant{0};
@@ -1508,9 +1524,8 @@ int32_t svs_index_info(const svs_index* idx, svs_index_info_t* out) {
   return SVS_OK;
 }
 
-int32_t svs_index_search(svs_index* idx, const float* queries, int32_t nq, int32_t d, int32_t k,
-                         float* out_scores, int64_t* out_rows, int32_t* out_count) {
-  if (!idx) return fail(SVS_ERR_INVALID, "null index");
+static int32_t search_host(svs_index* idx, const float* queries, int32_t nq, int32_t d, int32_t k,
+                           float* out_scores, int64_t* out_rows, int32_t* out_count) {
   RefGuard guard(idx);
   std::shared_lock<std::shared_mutex> geo(idx->rw);
   int rc = check_query_args(idx, queries, nq, d);
@@ -1568,6 +1583,100 @@ int32_t svs_index_search(svs_index* idx, const float* queries, int32_t nq, int32
     memcpy(out_scores + (size_t)qi * k, c->out_s_pin + (size_t)qi * count, (size_t)count * sizeof(float));
     memcpy(out_rows + (size_t)qi * k, c->out_r_pin + (size_t)qi * count, (size_t)count * sizeof(int64_t));
   }
+  return SVS_OK;
+}
+
+// One pass for everything that queued up while the device was busy.  The calling thread (the leader)
+// owns the pass: queries gathered into one batch, k = the largest asked for (a top-k list's first n
+// entries are the top-n list), results handed back to the waiters' own buffers.
+static void coalesced_pass(svs_index* idx, std::vector<svs_index::Waiter*>& batch, int d) {
+  const int nb = (int)batch.size();
+  int kmax = 0;
+  for (auto* w : batch) kmax = std::max(kmax, w->k);
+  int rc = SVS_OK;
+  int32_t count = 0;
+  std::vector<float> qs, ss;
+  std::vector<int64_t> rr;
+  try {
+    qs.resize((size_t)nb * d);
+    ss.resize((size_t)nb * kmax);
+    rr.resize((size_t)nb * kmax);
+  } catch (const std::bad_alloc&) {
+    rc = fail(SVS_ERR_NOMEM, "out of host memory for a coalesced pass");
+  }
+  if (rc == SVS_OK) {
+    for (int i = 0; i < nb; ++i) memcpy(qs.data() + (size_t)i * d, batch[i]->q, (size_t)d * sizeof(float));
+    rc = search_host(idx, qs.data(), nb, d, kmax, ss.data(), rr.data(), &count);
+  }
+  const std::string err = rc == SVS_OK ? std::string() : std::string(svs_last_error());
+  idx->co_passes.fetch_add(1);
+  idx->co_queries.fetch_add(nb);
+  std::lock_guard<std::mutex> lk(idx->co_mu);
+  for (int i = 0; i < nb; ++i) {
+    svs_index::Waiter* w = batch[i];
+    w->rc = rc;
+    if (rc == SVS_OK) {
+      w->count = std::min(w->k, (int)count);
+      memcpy(w->out_s, ss.data() + (size_t)i * kmax, (size_t)w->count * sizeof(float));
+      memcpy(w->out_r, rr.data() + (size_t)i * kmax, (size_t)w->count * sizeof(int64_t));
+    } else {
+      w->err = err;
+    }
+    w->done = true;
+    if (!w->lead) w->cv.notify_one();
+  }
+}
+
+int32_t svs_index_search(svs_index* idx, const float* queries, int32_t nq, int32_t d, int32_t k,
+                         float* out_scores, int64_t* out_rows, int32_t* out_count) {
+  if (!idx) return fail(SVS_ERR_INVALID, "null index");
+  // (only well-formed single queries are coalesced: every error stays with the call that made it)
+  if (!(idx->coalesce.load() && nq == 1 && k > 0 && d == idx->d && queries && out_scores && out_rows && idx->n > 0))
+    return search_host(idx, queries, nq, d, k, out_scores, out_rows, out_count);
+  RefGuard guard(idx);
+  svs_index::Waiter me;
+  me.q = queries; me.k = k; me.out_s = out_scores; me.out_r = out_rows;
+  {
+    std::unique_lock<std::mutex> lk(idx->co_mu);
+    idx->co_pending.push_back(&me);
+    if (!idx->co_busy) { idx->co_busy = true; me.lead = true; }
+    else me.cv.wait(lk, [&] { return me.done || me.lead; });
+  }
+  if (me.lead) {
+    // drive the device until this call's own query is answered, then hand over
+    std::vector<svs_index::Waiter*> batch;
+    while (!me.done) {
+      {
+        std::lock_guard<std::mutex> lk(idx->co_mu);
+        const size_t take = std::min<size_t>(idx->co_pending.size(), 256);
+        batch.assign(idx->co_pending.begin(), idx->co_pending.begin() + take);
+        idx->co_pending.erase(idx->co_pending.begin(), idx->co_pending.begin() + take);
+      }
+      coalesced_pass(idx, batch, d);
+    }
+    std::lock_guard<std::mutex> lk(idx->co_mu);
+    if (!idx->co_pending.empty()) {
+      idx->co_pending.front()->lead = true;   // (stays queued: its own loop takes it out)
+      idx->co_pending.front()->cv.notify_one();
+    } else {
+      idx->co_busy = false;
+    }
+  }
+  if (me.rc != SVS_OK) return fail(me.rc, "%s", me.err.c_str());
+  if (out_count) *out_count = me.count;
+  return SVS_OK;
+}
+
+int32_t svs_index_set_coalesce(svs_index* idx, int32_t enable) {
+  if (!idx) return fail(SVS_ERR_INVALID, "null index");
+  idx->coalesce.store(enable != 0);
+  return SVS_OK;
+}
+
+int32_t svs_index_coalesce_stats(svs_index* idx, int64_t* passes, int64_t* queries) {
+  if (!idx) return fail(SVS_ERR_INVALID, "null index");
+  if (passes) *passes = idx->co_passes.load();
+  if (queries) *queries = idx->co_queries.load();
   return SVS_OK;
 }
 

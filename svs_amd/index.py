@@ -217,7 +217,8 @@ class DeviceIndex:
         if q.ndim != 1:
             raise ValueError(f"query must be 1-D, got shape {q.shape}")
         s, r = self.search_batch(q[None, :], n)
-        return [(float(a), int(b)) for a, b in zip(s[0], r[0])]
+        # (tolist(): python floats -- the exact widening float(np.float32) does, src/svs/util.py:203 -- and ints in C)
+        return list(zip(s[0].astype(np.float64).tolist(), r[0].tolist()))
 
     def scores(self, query_vec: np.ndarray) -> np.ndarray:
         """The raw ``np.dot(M, q)`` vector, f32 (N,)."""
@@ -294,6 +295,16 @@ class DeviceIndex:
         _native.check(self._lib.svs_index_get_timing(self._handle(), C.byref(t)))
         self.last_dominant_ms_sum = float(t.dominant_ms_sum)   # the dominant kernel alone (bench.py's roofline)
         return float(t.score_ms_sum), float(t.select_ms_sum), int(t.launches)
+
+    def set_coalesce(self, enable: bool) -> None:
+        """Concurrent single-query searches on this handle share corpus passes (svs_index_set_coalesce)."""
+        _native.check(self._lib.svs_index_set_coalesce(self._handle(), 1 if enable else 0))
+
+    def coalesce_stats(self) -> Tuple[int, int]:
+        """(corpus passes, queries answered) through the coalescing path."""
+        p, q = C.c_int64(0), C.c_int64(0)
+        _native.check(self._lib.svs_index_coalesce_stats(self._handle(), C.byref(p), C.byref(q)))
+        return p.value, q.value
 
     def set_variant(self, variant: int) -> None:
         _native.check(self._lib.svs_index_set_variant(self._handle(), int(variant)))

@@ -129,7 +129,57 @@ def test_coalesced_retrieves_on_the_gpu(gpu):
     for i in range(len(qs)):
         assert [e for _, e in got[i]] == [e for _, e in want[i]], i
         assert np.max(np.abs(np.array([s for s, _ in got[i]]) - np.array([s for s, _ in want[i]]))) <= 1e-5
-    co = mat._coalescer
-    assert co.queries == len(qs) and co.batches < len(qs), (co.queries, co.batches)
-    print(f"{co.queries} searches in {co.batches} corpus passes")
+    passes, answered = mat.index.coalesce_stats()           # a DeviceIndex coalesces inside the library
+    assert answered == len(qs) and passes < len(qs), (answered, passes)
+    print(f"{answered} searches in {passes} corpus passes")
+    # the Python coalescer (what MultiDeviceIndex and other index types get) on the same index
+    from svs_amd.coalesce import SearchCoalescer
+    mat.index.set_coalesce(False)
+    co = SearchCoalescer()
+    idx = mat.index
+
+    def worker2(t):
+        for i in range(t, len(qs), 24):
+            got[i] = [(s, int(ids[r])) for s, r in co.search(idx, qs[i], 50)]
+
+    got = [None] * len(qs)
+    ts = [threading.Thread(target=worker2, args=(t,)) for t in range(24)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for i in range(len(qs)):
+        assert [e for _, e in got[i]] == [e for _, e in want[i]], i
+    assert co.queries == len(qs) and co.batches < len(qs)
     mat.invalidate()
+
+
+@pytest.mark.gpu
+def test_native_coalescing_errors_and_mixed_k(gpu):
+    """svs_index_set_coalesce: different k per caller, wrong dimension and k = 0 alongside, 32 threads."""
+    from svs_amd import DeviceIndex
+    from synth import corpus_and_query
+    m, qs = corpus_and_query("gaussian", 424242, 200000, 768, 64)
+    idx = DeviceIndex(m)
+    want = [idx.search(q, 5 + i % 90) for i, q in enumerate(qs)]
+    idx.set_coalesce(True)
+    got, errs = [None] * len(qs), []
+
+    def worker(t):
+        for rep in range(3):
+            for i in range(t, len(qs), 32):
+                got[i] = idx.search(qs[i], 5 + i % 90)
+            try:
+                idx.search(np.zeros(769, dtype=np.float32), 3)
+            except ValueError:
+                errs.append(t)
+            assert idx.search(qs[t], 0) == []
+
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(32)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert len(errs) == 32 * 3
+    for i in range(len(qs)):
+        assert [r for _, r in got[i]] == [r for _, r in want[i]], i
+        assert np.max(np.abs(np.array([s for s, _ in got[i]]) - np.array([s for s, _ in want[i]]))) <= 1e-5
+    passes, answered = idx.coalesce_stats()
+    assert answered == 3 * len(qs) and passes < answered
+    idx.release()

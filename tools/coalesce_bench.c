@@ -1,0 +1,76 @@
+/* Concurrent single-query callers of the C ABI (tools only): T threads call svs_index_search(nq = 1)
+ * back to back for a few seconds, without and with svs_index_set_coalesce.
+ *   build: gcc -O2 -I include tools/coalesce_bench.c -o tools/coalesce_bench_c -L svs_amd/lib -lsvs_amd -lpthread -lm -Wl,-rpath,$PWD/svs_amd/lib -Wl,-rpath,/opt/rocm/lib
+ *   usage: coalesce_bench_c [rows=1000000] [dim=1536] [seconds=3] */
+#include <math.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include "svs_amd.h"
+
+enum { NQ = 256, K = 100 };
+static svs_index* g_idx;
+static float* g_q;
+static int g_d;
+static volatile int g_stop;
+static long g_done[512];
+
+static double now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+
+static void* caller(void* arg) {
+  const long t = (long)arg;
+  float s[K];
+  int64_t r[K];
+  int32_t count;
+  long i = t, n = 0;
+  while (!g_stop) {
+    if (svs_index_search(g_idx, g_q + (size_t)(i % NQ) * g_d, 1, g_d, K, s, r, &count) != SVS_OK) { fprintf(stderr, "search: %s\n", svs_last_error()); exit(5); }
+    i += 7; ++n;
+  }
+  g_done[t] = n;
+  return NULL;
+}
+
+int main(int argc, char** argv) {
+  const long rows = argc > 1 ? atol(argv[1]) : 1000000;
+  const int d = argc > 2 ? atoi(argv[2]) : 1536;
+  const double secs = argc > 3 ? atof(argv[3]) : 3.0;
+  const int threads[] = {1, 4, 16, 64, 256};
+  float* m = (float*)malloc(sizeof(float) * (size_t)rows * d);
+  unsigned long long x = 88172645463325252ull;
+  size_t i;
+  int ti, mode;
+  g_d = d;
+  g_q = (float*)malloc(sizeof(float) * NQ * d);
+  if (!m || !g_q) return 2;
+  for (i = 0; i < (size_t)rows * d; ++i) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; m[i] = ((float)(x >> 40) / 8388608.0f - 1.0f) * 0.044f; }
+  for (i = 0; i < (size_t)NQ * d; ++i) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; g_q[i] = ((float)(x >> 40) / 8388608.0f - 1.0f) * 0.044f; }
+  if (svs_index_create(m, rows, d, SVS_DTYPE_F32, 0, 0, &g_idx) != SVS_OK) { fprintf(stderr, "create: %s\n", svs_last_error()); return 4; }
+  free(m);
+  for (ti = 0; ti < 5; ++ti)
+    for (mode = 0; mode < 2; ++mode) {
+      pthread_t th[512];
+      const int T = threads[ti];
+      long t, total = 0;
+      int64_t p0, q0, p1, q1;
+      double t0, dt;
+      svs_index_set_coalesce(g_idx, mode);
+      svs_index_coalesce_stats(g_idx, &p0, &q0);
+      g_stop = 0;
+      t0 = now();
+      for (t = 0; t < T; ++t) pthread_create(&th[t], NULL, caller, (void*)t);
+      while (now() - t0 < secs) { struct timespec ts = {0, 20000000}; nanosleep(&ts, NULL); }
+      g_stop = 1;
+      for (t = 0; t < T; ++t) { pthread_join(th[t], NULL); total += g_done[t]; }
+      dt = now() - t0;
+      svs_index_coalesce_stats(g_idx, &p1, &q1);
+      printf("%3d threads %-9s: %9.0f queries/s  (mean latency %.2f ms", T, mode ? "coalesced" : "solo", total / dt, 1e3 * dt * T / (double)total);
+      if (mode) printf(", %.1f queries per corpus pass", (double)(q1 - q0) / (double)(p1 - p0 > 0 ? p1 - p0 : 1));
+      printf(")\n");
+      fflush(stdout);
+    }
+  svs_index_release(g_idx);
+  return 0;
+}

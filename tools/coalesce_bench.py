@@ -21,8 +21,10 @@ for r0 in range(0, n, 250000):
 qs = torch.randn((256, d), device=dev, generator=g); qs /= qs.norm(dim=1, keepdim=True)
 qh = qs.cpu().numpy()
 for T in threads:
-    for mode in ("solo", "coalesced"):
+    for mode in ("solo", "coalesced", "native"):
         co = SearchCoalescer() if mode == "coalesced" else None
+        idx.set_coalesce(mode == "native")
+        p0, q0 = idx.coalesce_stats()
         done, lat, stop = [0] * T, [[] for _ in range(T)], time.time() + secs
         def worker(t):
             i = t
@@ -36,5 +38,8 @@ for T in threads:
         t0 = time.time(); [t.start() for t in ts]; [t.join() for t in ts]; dt = time.time() - t0
         all_lat = np.sort(np.concatenate([np.array(x) for x in lat])) * 1e3
         extra = f", {co.queries / max(co.batches, 1):.1f} queries per corpus pass" if co is not None else ""
+        if mode == "native":
+            p1, q1 = idx.coalesce_stats()
+            extra = f", {(q1 - q0) / max(p1 - p0, 1):.1f} queries per corpus pass (inside the library)"
         print(f"{T:3d} threads {mode:9s}: {sum(done) / dt:9.0f} queries/s, latency p50 {all_lat[len(all_lat) // 2]:.2f} ms p99 {all_lat[int(len(all_lat) * 0.99)]:.2f} ms{extra}", flush=True)
 idx.release()
