@@ -134,6 +134,7 @@ struct svs_index {
     std::condition_variable cv;
   };
   std::atomic<bool> coalesce{false};
+  std::atomic<bool> co_round{true};
   std::mutex co_mu;
   std::vector<Waiter*> co_pending;
   bool co_busy = false;
@@ -1648,7 +1649,12 @@ int32_t svs_index_search(svs_index* idx, const float* queries, int32_t nq, int32
     while (!me.done) {
       {
         std::lock_guard<std::mutex> lk(idx->co_mu);
-        const size_t take = std::min<size_t>(idx->co_pending.size(), 256);
+        // whole kernel tiles: the batched kernels cost the same for 33 queries as for 64 (f32: 1.8 vs 1.2 ms for
+        // 32), so a queue that does not fill the next tile size leaves its tail for the following pass
+        size_t take = std::min<size_t>(idx->co_pending.size(), 256);
+        if (idx->co_round.load())
+          for (size_t g : {(size_t)128, (size_t)64, (size_t)32, (size_t)16})
+            if (take > g && take < 2 * g) { take = g; break; }
         batch.assign(idx->co_pending.begin(), idx->co_pending.begin() + take);
         idx->co_pending.erase(idx->co_pending.begin(), idx->co_pending.begin() + take);
       }
@@ -1670,6 +1676,7 @@ int32_t svs_index_search(svs_index* idx, const float* queries, int32_t nq, int32
 int32_t svs_index_set_coalesce(svs_index* idx, int32_t enable) {
   if (!idx) return fail(SVS_ERR_INVALID, "null index");
   idx->coalesce.store(enable != 0);
+  idx->co_round.store(enable != 2);   // (2: take everything that is queued, whatever the tile sizes -- A/B)
   return SVS_OK;
 }
 

@@ -50,7 +50,7 @@ int main(int argc, char** argv) {
   if (svs_index_create(m, rows, d, SVS_DTYPE_F32, 0, 0, &g_idx) != SVS_OK) { fprintf(stderr, "create: %s\n", svs_last_error()); return 4; }
   free(m);
   for (ti = 0; ti < 5; ++ti)
-    for (mode = 0; mode < 2; ++mode) {
+    for (mode = 0; mode < 3; ++mode) {
       pthread_t th[512];
       const int T = threads[ti];
       long t, total = 0;
@@ -66,7 +66,7 @@ int main(int argc, char** argv) {
       for (t = 0; t < T; ++t) { pthread_join(th[t], NULL); total += g_done[t]; }
       dt = now() - t0;
       svs_index_coalesce_stats(g_idx, &p1, &q1);
-      printf("%3d threads %-9s: %9.0f queries/s  (mean latency %.2f ms", T, mode ? "coalesced" : "solo", total / dt, 1e3 * dt * T / (double)total);
+      printf("%3d threads %-9s: %9.0f queries/s  (mean latency %.2f ms", T, mode == 0 ? "solo" : (mode == 1 ? "coalesced" : "coal. all"), total / dt, 1e3 * dt * T / (double)total);
       if (mode) printf(", %.1f queries per corpus pass", (double)(q1 - q0) / (double)(p1 - p0 > 0 ? p1 - p0 : 1));
       printf(")\n");
       fflush(stdout);
