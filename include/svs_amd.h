@@ -224,6 +224,10 @@ int32_t svs_multi_retain(svs_multi* m);
 int32_t svs_multi_release(svs_multi* m);
 /* Shard count, total rows (masked ones included), dimension, masked rows; any pointer may be NULL. */
 int32_t svs_multi_info(svs_multi* m, int32_t* ndev, int64_t* n, int32_t* d, int64_t* n_masked);
+/* As svs_index_set_coalesce, in front of the shards: concurrent single-query svs_multi_search calls are
+ * answered together by one batched search per shard. */
+int32_t svs_multi_set_coalesce(svs_multi* m, int32_t enable);
+int32_t svs_multi_coalesce_stats(svs_multi* m, int64_t* passes, int64_t* queries);
 /* Shard g as an ordinary index handle (one more reference: release it with svs_index_release),
  * e.g. for svs_index_mask_rows / svs_index_info on the shard that holds a row. */
 int32_t svs_multi_shard(svs_multi* m, int32_t g, svs_index** out);

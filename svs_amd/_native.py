@@ -69,6 +69,8 @@ SIGNATURES = {
     "svs_multi_retain": (C.c_int32, [_P]),
     "svs_multi_release": (C.c_int32, [_P]),
     "svs_multi_info": (C.c_int32, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    "svs_multi_set_coalesce": (C.c_int32, [_P, C.c_int32]),
+    "svs_multi_coalesce_stats": (C.c_int32, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "svs_multi_shard": (C.c_int32, [_P, C.c_int32, C.POINTER(_P)]),
     "svs_index_mask_rows": (C.c_int32, [_P, _P, C.c_int64]),
     "svs_index_retain": (C.c_int32, [_P]),

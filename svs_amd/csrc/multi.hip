@@ -19,6 +19,7 @@
 #include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
+#include <cstring>
 #include <deque>
 #include <functional>
 #include <memory>
@@ -69,11 +70,26 @@ struct Latch {
 
 }  // namespace
 
+struct MultiWaiter {   // one queued single-query call (svs_multi_set_coalesce)
+  const float* q;
+  int k, count = 0, rc = SVS_OK;
+  float* out_s;
+  int64_t* out_r;
+  std::string err;
+  bool done = false, lead = false;
+  std::condition_variable cv;
+};
+
 struct svs_multi {
   std::vector<svs_index*> shards;
   std::vector<Worker*> workers;
   std::atomic<int> refs{1};
   int32_t d = 0;
+  std::atomic<bool> coalesce{false};
+  std::mutex co_mu;
+  std::vector<MultiWaiter*> co_pending;
+  bool co_busy = false;
+  std::atomic<int64_t> co_passes{0}, co_queries{0};
 };
 
 namespace {
@@ -183,9 +199,8 @@ int32_t svs_multi_shard(svs_multi* m, int32_t g, svs_index** out) {
   return SVS_OK;
 }
 
-int32_t svs_multi_search(svs_multi* m, const float* queries, int32_t nq, int32_t d, int32_t k, float* out_scores,
-                         int64_t* out_rows, int32_t* out_count) {
-  if (!m) return refail(SVS_ERR_INVALID, "null handle");
+static int32_t multi_search_impl(svs_multi* m, const float* queries, int32_t nq, int32_t d, int32_t k, float* out_scores,
+                                 int64_t* out_rows, int32_t* out_count) {
   m->refs.fetch_add(1);
   struct Unref { svs_multi* m; ~Unref() { svs_multi_release(m); } } unref{m};
   const int G = (int)m->shards.size();
@@ -261,6 +276,101 @@ int32_t svs_multi_search(svs_multi* m, const float* queries, int32_t nq, int32_t
       out_rows[(size_t)qi * kk + o] = part[best].r[at];
     }
   }
+  return SVS_OK;
+}
+
+// Concurrent single-query callers share passes over ALL shards: the protocol of svs_index_set_coalesce
+// (svs_amd.hip), one level up -- the queue is in front of the shard workers, so one batched search per
+// shard serves everybody who queued up while the devices were busy.
+static void multi_coalesced_pass(svs_multi* m, std::vector<MultiWaiter*>& batch, int d) {
+  const int nb = (int)batch.size();
+  int kmax = 0;
+  for (auto* w : batch) kmax = std::max(kmax, w->k);
+  int rc = SVS_OK;
+  int32_t count = 0;
+  std::vector<float> qs, ss;
+  std::vector<int64_t> rr;
+  try {
+    qs.resize((size_t)nb * d);
+    ss.resize((size_t)nb * kmax);
+    rr.resize((size_t)nb * kmax);
+  } catch (const std::bad_alloc&) {
+    rc = refail(SVS_ERR_NOMEM, "out of host memory for a coalesced pass");
+  }
+  if (rc == SVS_OK) {
+    for (int i = 0; i < nb; ++i) memcpy(qs.data() + (size_t)i * d, batch[i]->q, (size_t)d * sizeof(float));
+    rc = multi_search_impl(m, qs.data(), nb, d, kmax, ss.data(), rr.data(), &count);
+  }
+  const std::string err = rc == SVS_OK ? std::string() : std::string(svs_last_error());
+  m->co_passes.fetch_add(1);
+  m->co_queries.fetch_add(nb);
+  std::lock_guard<std::mutex> lk(m->co_mu);
+  for (int i = 0; i < nb; ++i) {
+    MultiWaiter* w = batch[i];
+    w->rc = rc;
+    if (rc == SVS_OK) {
+      w->count = std::min(w->k, (int)count);
+      memcpy(w->out_s, ss.data() + (size_t)i * kmax, (size_t)w->count * sizeof(float));
+      memcpy(w->out_r, rr.data() + (size_t)i * kmax, (size_t)w->count * sizeof(int64_t));
+    } else {
+      w->err = err;
+    }
+    w->done = true;
+    if (!w->lead) w->cv.notify_one();
+  }
+}
+
+int32_t svs_multi_search(svs_multi* m, const float* queries, int32_t nq, int32_t d, int32_t k, float* out_scores,
+                         int64_t* out_rows, int32_t* out_count) {
+  if (!m) return refail(SVS_ERR_INVALID, "null handle");
+  if (!(m->coalesce.load() && nq == 1 && k > 0 && d == m->d && queries && out_scores && out_rows))
+    return multi_search_impl(m, queries, nq, d, k, out_scores, out_rows, out_count);
+  m->refs.fetch_add(1);
+  struct Unref { svs_multi* m; ~Unref() { svs_multi_release(m); } } unref{m};
+  MultiWaiter me;
+  me.q = queries; me.k = k; me.out_s = out_scores; me.out_r = out_rows;
+  {
+    std::unique_lock<std::mutex> lk(m->co_mu);
+    m->co_pending.push_back(&me);
+    if (!m->co_busy) { m->co_busy = true; me.lead = true; }
+    else me.cv.wait(lk, [&] { return me.done || me.lead; });
+  }
+  if (me.lead) {
+    std::vector<MultiWaiter*> batch;
+    while (!me.done) {
+      {
+        std::lock_guard<std::mutex> lk(m->co_mu);
+        size_t take = std::min<size_t>(m->co_pending.size(), 256);
+        for (size_t g : {(size_t)128, (size_t)64, (size_t)32, (size_t)16})   // whole kernel tiles (svs_amd.hip)
+          if (take > g && take < 2 * g) { take = g; break; }
+        batch.assign(m->co_pending.begin(), m->co_pending.begin() + take);
+        m->co_pending.erase(m->co_pending.begin(), m->co_pending.begin() + take);
+      }
+      multi_coalesced_pass(m, batch, d);
+    }
+    std::lock_guard<std::mutex> lk(m->co_mu);
+    if (!m->co_pending.empty()) {
+      m->co_pending.front()->lead = true;
+      m->co_pending.front()->cv.notify_one();
+    } else {
+      m->co_busy = false;
+    }
+  }
+  if (me.rc != SVS_OK) return refail(me.rc, me.err);
+  if (out_count) *out_count = me.count;
+  return SVS_OK;
+}
+
+int32_t svs_multi_set_coalesce(svs_multi* m, int32_t enable) {
+  if (!m) return refail(SVS_ERR_INVALID, "null handle");
+  m->coalesce.store(enable != 0);
+  return SVS_OK;
+}
+
+int32_t svs_multi_coalesce_stats(svs_multi* m, int64_t* passes, int64_t* queries) {
+  if (!m) return refail(SVS_ERR_INVALID, "null handle");
+  if (passes) *passes = m->co_passes.load();
+  if (queries) *queries = m->co_queries.load();
   return SVS_OK;
 }
 

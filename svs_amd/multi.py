@@ -252,6 +252,16 @@ class NativeMultiIndex:
             finally:
                 self._lib.svs_index_release(h)
 
+    def set_coalesce(self, enable: bool) -> None:
+        """Concurrent single-query searches share passes over all shards (svs_multi_set_coalesce)."""
+        self._native.check(self._lib.svs_multi_set_coalesce(self._h, 1 if enable else 0))
+
+    def coalesce_stats(self) -> Tuple[int, int]:
+        C = self._C
+        p, q = C.c_int64(0), C.c_int64(0)
+        self._native.check(self._lib.svs_multi_coalesce_stats(self._h, C.byref(p), C.byref(q)))
+        return p.value, q.value
+
     def release(self) -> None:
         if self._h:
             self._lib.svs_multi_release(self._h)

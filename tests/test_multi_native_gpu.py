@@ -77,5 +77,22 @@ def test_native_multi_concurrent_callers(gpu):
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert not bad
+    # the same with coalescing in front of the shards: rows as before, scores within the summation noise
+    multi.set_coalesce(True)
+    bad2 = []
+
+    def worker2(t):
+        for rep in range(6):
+            for qi in range(t, len(qs), 12):
+                got = multi.search(qs[qi], 30)
+                if [r for _, r in got] != [r for _, r in exp[qi]] or max(abs(a - b) for (a, _), (b, _) in zip(got, exp[qi])) > 1e-5:
+                    bad2.append((t, qi))
+
+    ts = [threading.Thread(target=worker2, args=(t,)) for t in range(12)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not bad2
+    passes, answered = multi.coalesce_stats()
+    assert answered == 6 * len(qs) and passes < answered
     one.release()
     multi.release()
