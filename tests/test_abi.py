@@ -78,7 +78,7 @@ def test_header_is_plain_c_and_links(tmp_path):
     assert out.returncode == 0 and "svs_amd" in out.stdout, (out.returncode, out.stdout, out.stderr)
 
 
-def _build_c(tmp_path, name, extra=()):
+def _build_c(tmp_path, name, extra=("-lm",)):
     import subprocess
     lib_dir = os.path.join(ROOT, "svs_amd", "lib")
     exe = tmp_path / name
@@ -123,3 +123,13 @@ def test_c_caller_multi_device(gpu, tmp_path):
     exe = _build_c(tmp_path, "multi_device")
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.startswith("ok"), (out.returncode, out.stdout, out.stderr)
+
+
+@pytest.mark.gpu
+def test_c_callers_coalesce(gpu, tmp_path):
+    """24 C threads on one handle with svs_index_set_coalesce (tests/c/coalesce.c)."""
+    import subprocess
+    exe = _build_c(tmp_path, "coalesce")
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.startswith("ok"), (out.returncode, out.stdout, out.stderr)
+    print(out.stdout.strip())
