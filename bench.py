@@ -129,6 +129,8 @@ def main():
                     help="N > 1: steps whose local top-k records share one RCCL all-gather")
     ap.add_argument("--batch", default="16,256",
                     help="queries per call of the secondary batched figures, comma separated (0: skip)")
+    ap.add_argument("--concurrent", type=int, default=64,
+                    help="threads of the secondary concurrent-callers figure (0: skip)")
     ap.add_argument("--configs", default="2,4",
                     help="BASELINE.json batch configs measured as secondary figures at N = 1 (2: 1M x 1536 f16 x 1024 "
                          "queries; 4: 10M x 3072 fp8 x 256 queries; empty: skip)")
@@ -313,6 +315,42 @@ def main():
                             "note": "host API (queries in, results out, synchronised)"})
     idx.set_timing(False)
 
+    # ---- secondary figure (N = 1 only; not `value`): CONCURRENT single-query callers, the way AsyncKB.retrieve
+    # meets the search (one executor thread per task, reference src/svs/kb.py:1184-1190): without and with
+    # svs_index_set_coalesce.  Python threads, so the GIL caps it (~12 k queries/s; 64 C threads reach 24.6 k:
+    # tools/coalesce_bench.c)
+    concurrent = None
+    if world == 1 and args.concurrent > 1 and n_local * d:
+        import threading
+        gc = torch.Generator(device=dev)
+        gc.manual_seed(args.seed + 4242)
+        qc = torch.randn((256, d), device=dev, dtype=torch.float32, generator=gc)
+        qc = (qc / qc.norm(dim=1, keepdim=True)).cpu().numpy()
+        concurrent = {"callers": args.concurrent, "unit": "queries/s", "note": "Python threads, one query per call, host API"}
+        for mode in ("solo", "coalesced"):
+            idx.set_coalesce(mode == "coalesced")
+            p0, a0 = idx.coalesce_stats()
+            done = [0] * args.concurrent
+            stop = time.time() + 1.5
+
+            def caller(t):
+                i = t
+                while time.time() < stop:
+                    idx.search(qc[i % 256], k)
+                    i += args.concurrent
+                    done[t] += 1
+            ts = [threading.Thread(target=caller, args=(t,)) for t in range(args.concurrent)]
+            t0 = time.time()
+            [t.start() for t in ts]
+            [t.join() for t in ts]
+            dt = time.time() - t0
+            concurrent[mode] = sum(done) / dt
+            concurrent[mode + "_mean_latency_ms"] = 1e3 * dt * args.concurrent / max(sum(done), 1)
+            if mode == "coalesced":
+                p1, a1 = idx.coalesce_stats()
+                concurrent["queries_per_corpus_pass"] = (a1 - a0) / max(p1 - p0, 1)
+        idx.set_coalesce(False)
+
     # ---- secondary figures (N = 1 only; not `value`): BASELINE.json configs[2] and configs[4], the
     # MFMA-bound batch configurations, each on its own index (synthetic, same recipe as the headline corpus)
     configs = []
@@ -372,6 +410,7 @@ def main():
             "p50_latency_ms": lat_ms,
             "sharded_check": sharded_check,
             "batched": batched,
+            "concurrent": concurrent,
             "configs": configs,
             "stage_ms": {"score": kernel_ms, "select": select_ms / max(launches, 1)},
             "roofline": {
