@@ -284,3 +284,54 @@ def test_pipelined_exchange_world1_equals_search(gpu):
     assert np.array_equal(bs, ws) and np.array_equal(br, wr)
     assert sh.search(qs[3], 7) == idx.search(qs[3], 7)
     idx.release()
+
+
+def _nccl_world1_worker(port, out_q):
+    """Child process: RCCL itself (backend "nccl") with one rank on cuda:0 -- process-group init with a
+    device id, all_gather_into_tensor on HBM records (blocking and async_op), the host merge."""
+    import os
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    try:
+        import torch
+        import torch.distributed as dist
+        from svs_amd import DeviceIndex
+        from svs_amd.sharded import ShardedIndex
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+        n, d, k = 50000, 1536, 100
+        m, qs = corpus_and_query("gaussian", 53, n, d, 19)
+        idx = DeviceIndex(m, row_offset=123_000)
+        sh = ShardedIndex(idx, n_total=n, device=dev, gather_every=8, streams=2)
+        qt = torch.from_numpy(qs).to(dev)
+        sh.open(len(qs), k)
+        for i in range(len(qs)):
+            sh.enqueue(qt[i].data_ptr(), d)
+        res = sh.collect()
+        ok = True
+        for i, (s, r) in enumerate(res):
+            one = idx.search(qs[i], k)
+            ok &= [int(x) for x in r] == [x for _, x in one] and [float(x) for x in s] == [x for x, _ in one]
+        bs, br = sh.search_batch(qs, k)
+        ws, wr = idx.search_batch(qs, k)
+        ok &= bool(np.array_equal(bs, ws) and np.array_equal(br, wr))
+        idx.release()
+        dist.destroy_process_group()
+        out_q.put("ok" if ok else "results differ")
+    except BaseException as e:   # noqa: BLE001
+        out_q.put(f"{type(e).__name__}: {e}")
+
+
+@pytest.mark.gpu
+def test_pipelined_exchange_over_rccl_world1(gpu):
+    """The exchange on the REAL backend: the multi-GPU tests above run gloo (CPU tensors allowed, no device
+    binding); this one initialises RCCL with a device id and gathers CUDA tensors, on the one rank the box has.
+    In a child process: a process group is per process, and RCCL should not live in the test runner."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_world1_worker, args=(29533, q))
+    p.start()
+    p.join(timeout=600)
+    assert not p.is_alive(), "RCCL worker hung"
+    assert q.get(timeout=5) == "ok"
