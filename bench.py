@@ -155,12 +155,17 @@ def main():
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    # SVS_BENCH_FORCE_DIST=1 (rehearsal only, N = 1): the N > 1 code path -- RCCL process group, records in HBM,
+    # one all-gather per `gather_every` steps, async copy home -- with the one rank a 1-GPU box has
+    force_dist = world == 1 and bool(os.environ.get("SVS_BENCH_FORCE_DIST"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+    elif force_dist:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29577", rank=0, world_size=1, device_id=dev)
 
     d, k, K, W = args.dim, args.k, args.steps, args.warmup
     if args.scaling == "strong":
@@ -195,7 +200,7 @@ def main():
     # all-gather per `gather_every` steps on alternating HIP streams, rank 0 streams each gathered
     # chunk home with an async copy and merges (host merge, H1).
     sh = ShardedIndex(idx, n_total, device=dev, gather_every=args.gather_every,
-                      streams=(args.inflight if world == 1 else max(2, args.inflight)))
+                      streams=(args.inflight if world == 1 else max(2, args.inflight)), force_collective=force_dist)
     G = sh.gather_every
     count = min(k, n_local)
     torch.cuda.synchronize()
@@ -405,7 +410,7 @@ def main():
                 "rows_per_gpu": n_local, "dim": d, "k": k, "queries_per_step": 1,
                 "corpus": "unit-norm gaussian, seed %d, generated on device" % args.seed,
                 "variant": args.variant, "searches_in_flight": sh.streams,
-                "steps_per_exchange": G if world > 1 else None,
+                "steps_per_exchange": G if (world > 1 or force_dist) else None,
             },
             "p50_latency_ms": lat_ms,
             "sharded_check": sharded_check,
@@ -469,7 +474,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     idx.release()
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

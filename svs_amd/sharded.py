@@ -112,7 +112,7 @@ class ShardedIndex:
     elsewhere) and are identical for every G: a row's score does not depend on where it lives."""
 
     def __init__(self, local, n_total: int, group=None, dst: int = 0, device=None, *,
-                 gather_every: int = 8, streams: int = 2):
+                 gather_every: int = 8, streams: int = 2, force_collective: bool = False):
         import torch.distributed as dist
         self._dist = dist
         self.local = local
@@ -124,8 +124,12 @@ class ShardedIndex:
         self.device = device
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.gather_every = max(1, int(gather_every)) if self.world > 1 else 1
-        self._n_streams = max(1, int(streams)) if self.world == 1 else max(2, int(streams))
+        # one rank needs no exchange (records go straight to pinned host memory); `force_collective` takes the
+        # N > 1 path anyway -- records in HBM, RCCL all-gather, async copy home -- so that the real backend can be
+        # exercised on a one-GPU box (tests)
+        self._multi = self.world > 1 or (bool(force_collective) and dist.is_initialized())
+        self.gather_every = max(1, int(gather_every)) if self._multi else 1
+        self._n_streams = max(1, int(streams)) if not self._multi else max(2, int(streams))
         self._pipe = None
         self._rec_cache = {}
 
@@ -133,7 +137,7 @@ class ShardedIndex:
     def _exchange(self, rec):
         """rec: uint8 tensor (record bytes) of this rank -> uint8 (world, record bytes) on dst, else None."""
         import torch
-        if self.world == 1:
+        if not self._multi:
             return rec[None]
         out = torch.empty((self.world, rec.numel()), dtype=torch.uint8, device=rec.device)
         self._dist.all_gather_into_tensor(out.view(-1), rec, group=self.group)
@@ -190,8 +194,8 @@ class ShardedIndex:
              # (zero-copy, no D2H).  N > 1: records stay in HBM for the RCCL all-gather; dst streams
              # each gathered chunk home with an async copy.
              "host": torch.zeros((nchunks, self.world, g * rec), dtype=torch.uint8, pin_memory=True),
-             "local": None if self.world == 1 else torch.zeros((nchunks, g * rec), device=dev, dtype=torch.uint8),
-             "gathered": None if self.world == 1 else torch.zeros((nchunks, self.world, g * rec), device=dev, dtype=torch.uint8),
+             "local": None if not self._multi else torch.zeros((nchunks, g * rec), device=dev, dtype=torch.uint8),
+             "gathered": None if not self._multi else torch.zeros((nchunks, self.world, g * rec), device=dev, dtype=torch.uint8),
              "streams": [torch.cuda.Stream(device=dev) for _ in range(self._n_streams)]}
         self._pipe = p
 
@@ -221,10 +225,10 @@ class ShardedIndex:
         c, j = divmod(i, g)
         assert c < p["nchunks"], "ShardedIndex.open(capacity) exceeded"
         st = p["streams"][i % len(p["streams"])]
-        base = (p["host"][c, 0] if self.world == 1 else p["local"][c]).data_ptr() + j * p["rec"]
+        base = (p["host"][c, 0] if not self._multi else p["local"][c]).data_ptr() + j * p["rec"]
         self.local.search_device(query_ptr, 1, d, p["k"], base, base + p["s_bytes"], st.cuda_stream)
         p["n"] = i + 1
-        if self.world > 1 and j == g - 1:
+        if self._multi and j == g - 1:
             self._send_chunk(c, st)
         return i
 
@@ -235,7 +239,7 @@ class ShardedIndex:
         import torch
         p = self._pipe
         g = self.gather_every
-        if self.world > 1 and p["n"] > p["sent"] * g:
+        if self._multi and p["n"] > p["sent"] * g:
             last = p["n"] - 1
             self._send_chunk(last // g, p["streams"][last % len(p["streams"])])
         torch.cuda.synchronize(self.device)
@@ -247,7 +251,7 @@ class ShardedIndex:
         for i in range(first, p["n"]):
             c, j = divmod(i, g)
             sc, rw = unpack_records(p["host"][c].numpy()[:, j * rec:(j + 1) * rec], self.world, k)
-            if self.world == 1:
+            if not self._multi:
                 out.append((sc[0, :count].copy(), rw[0, :count].copy()))
             else:
                 out.append(merge_topk(sc, rw, count))

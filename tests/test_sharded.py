@@ -302,7 +302,9 @@ def _nccl_world1_worker(port, out_q):
         n, d, k = 50000, 1536, 100
         m, qs = corpus_and_query("gaussian", 53, n, d, 19)
         idx = DeviceIndex(m, row_offset=123_000)
-        sh = ShardedIndex(idx, n_total=n, device=dev, gather_every=8, streams=2)
+        # (force_collective: one rank would otherwise skip the exchange altogether)
+        sh = ShardedIndex(idx, n_total=n, device=dev, gather_every=8, streams=2, force_collective=True)
+        assert sh.gather_every == 8 and sh.streams >= 2
         qt = torch.from_numpy(qs).to(dev)
         sh.open(len(qs), k)
         for i in range(len(qs)):
