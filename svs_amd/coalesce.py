@@ -59,7 +59,7 @@ class SearchCoalescer:
         ``index`` is the caller's own reference to the generation's index."""
         assert isinstance(n, int)
         q = np.asarray(query_vec, dtype=np.float32)
-        if n <= 0 or q.ndim != 1 or q.shape[0] != getattr(index, "d", -1) or not hasattr(index, "search_batch"):
+        if n <= 0 or n > 2048 or q.ndim != 1 or q.shape[0] != getattr(index, "d", -1) or not hasattr(index, "search_batch"):
             return index.search(query_vec, n)          # (errors and empty answers stay the caller's own)
         req = _Req(q, n)
         with self._mu:

@@ -323,7 +323,7 @@ static void multi_coalesced_pass(svs_multi* m, std::vector<MultiWaiter*>& batch,
 int32_t svs_multi_search(svs_multi* m, const float* queries, int32_t nq, int32_t d, int32_t k, float* out_scores,
                          int64_t* out_rows, int32_t* out_count) {
   if (!m) return refail(SVS_ERR_INVALID, "null handle");
-  if (!(m->coalesce.load() && nq == 1 && k > 0 && d == m->d && queries && out_scores && out_rows))
+  if (!(m->coalesce.load() && nq == 1 && k > 0 && k <= 2048 && d == m->d && queries && out_scores && out_rows))
     return multi_search_impl(m, queries, nq, d, k, out_scores, out_rows, out_count);
   m->refs.fetch_add(1);
   struct Unref { svs_multi* m; ~Unref() { svs_multi_release(m); } } unref{m};

@@ -1632,7 +1632,8 @@ int32_t svs_index_search(svs_index* idx, const float* queries, int32_t nq, int32
                          float* out_scores, int64_t* out_rows, int32_t* out_count) {
   if (!idx) return fail(SVS_ERR_INVALID, "null index");
   // (only well-formed single queries are coalesced: every error stays with the call that made it)
-  if (!(idx->coalesce.load() && nq == 1 && k > 0 && d == idx->d && queries && out_scores && out_rows && idx->n > 0))
+  // (and only ordinary k: a "rank everything" call must not size a whole pass's buffers)
+  if (!(idx->coalesce.load() && nq == 1 && k > 0 && k <= 2048 && d == idx->d && queries && out_scores && out_rows && idx->n > 0))
     return search_host(idx, queries, nq, d, k, out_scores, out_rows, out_count);
   RefGuard guard(idx);
   svs_index::Waiter me;
