@@ -148,6 +148,7 @@ class DeviceEmbeddingsMatrix:
         except BaseException:
             idx.release()
             raise
+        self._apply_coalesce(idx)
         with self._mu:
             self.index = idx
             self._lookup = _Lookup(ids_all)
@@ -155,8 +156,16 @@ class DeviceEmbeddingsMatrix:
             self.embeddings_matrix = None
         return idx
 
+    def _apply_coalesce(self, idx) -> None:
+        """Switch the library's coalescing on for a freshly built index (so that the zero-diff
+        ``attach()`` path, which reaches the index through np.dot / np.argpartition, gets it too)."""
+        if hasattr(idx, "set_coalesce"):
+            idx.set_coalesce(bool(self.coalesce))
+            idx._coalesce_applied = bool(self.coalesce)
+
     def _install(self, matrix: np.ndarray, lookup: np.ndarray):
         idx = self._index_factory(matrix, device=self.device)
+        self._apply_coalesce(idx)
         with self._mu:
             self.index = idx
             self._lookup = _Lookup(lookup)
