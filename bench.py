@@ -129,6 +129,8 @@ def main():
                     help="N > 1: steps whose local top-k records share one RCCL all-gather")
     ap.add_argument("--batch", default="16,256",
                     help="queries per call of the secondary batched figures, comma separated (0: skip)")
+    ap.add_argument("--concurrent-solo", action="store_true",
+                    help="also time the concurrent callers WITHOUT coalescing")
     ap.add_argument("--concurrent", type=int, default=64,
                     help="threads of the secondary concurrent-callers figure (0: skip)")
     ap.add_argument("--configs", default="2,4",
@@ -332,7 +334,10 @@ def main():
         qc = torch.randn((256, d), device=dev, dtype=torch.float32, generator=gc)
         qc = (qc / qc.norm(dim=1, keepdim=True)).cpu().numpy()
         concurrent = {"callers": args.concurrent, "unit": "queries/s", "note": "Python threads, one query per call, host API"}
-        for mode in ("solo", "coalesced"):
+        # (the solo figure is opt-in: 64 uncoordinated callers put 8 score kernels on the card at once, each
+        #  several times slower than alone -- that would sit in the kernel statistics of the dominant kernel that
+        #  profiles/ records for this very command; alone they get `value`, ~1,140 queries/s, whatever their number)
+        for mode in (("solo", "coalesced") if args.concurrent_solo else ("coalesced",)):
             idx.set_coalesce(mode == "coalesced")
             p0, a0 = idx.coalesce_stats()
             done = [0] * args.concurrent
