@@ -116,7 +116,7 @@ int run(int64_t n, int d, int nq, int rounds) {
   struct V { const char* name; Fn fn; };
   const V vs[] = {{"round-1 tiled 256x256", launch_tiled<EB>}, {"phased", launch_phased<EB, 0>}, {"phased, no LDS-DMA in loop", launch_phased<EB, 1>},
                   {"phased, no fragment reads", launch_phased<EB, 2>}, {"phased, no MFMA", launch_phased<EB, 3>},
-                  {"phased, no stagger", launch_phased<EB, 7>}, {"phased, LDS-DMA + barriers only", launch_phased<EB, 5>}, {"phased, DMA pieces with the reads", launch_phased<EB, 30>}, {"phased, always k-tile 0 (L2 hits)", launch_phased<EB, 21>}, {"phased, DMA + barriers only, always k-tile 0", launch_phased<EB, 25>}, {"phased, barriers only", launch_phased<EB, 26>}, {"phased, epilogue with a branch per register", launch_phased<EB, 31>}, {"phased, corpus pieces nontemporal", launch_phased<EB, 20>}, {"phased, no epilogue", launch_phased<EB, 14>}};
+                  {"phased, no stagger", launch_phased<EB, 7>}, {"phased, LDS-DMA + barriers only", launch_phased<EB, 5>}, {"phased, DMA pieces between the MFMAs", launch_phased<EB, 30>}, {"phased, always k-tile 0 (L2 hits)", launch_phased<EB, 21>}, {"phased, DMA + barriers only, always k-tile 0", launch_phased<EB, 25>}, {"phased, barriers only", launch_phased<EB, 26>}, {"phased, epilogue with a branch per register", launch_phased<EB, 31>}, {"phased, corpus pieces nontemporal", launch_phased<EB, 20>}, {"phased, no epilogue", launch_phased<EB, 14>}};
   const int NVALL = sizeof(vs) / sizeof(vs[0]);
   const char* only = getenv("PGB_ONLY");          // e.g. PGB_ONLY=2 runs variant 2 alone (fault hunting)
   V sel[16]; int NV = 0;
