@@ -46,6 +46,8 @@
 
 namespace svs {
 
+typedef float f32x2_t __attribute__((ext_vector_type(2)));   // (also in fp8.h)
+
 constexpr int PG_TILE = 256;              // rows and queries per output tile
 constexpr int PG_SLOT = 1024;             // u32x4 per slot (16 KiB)
 constexpr int PG_LDS_BYTES = 8 * PG_SLOT * 16;
@@ -183,22 +185,35 @@ struct PgTile {
 // Fragment reads: inline asm with base + immediate offset.  Left to itself hipcc hoists all 48
 // fragment addresses of the two k-tile bodies out of the loop as separate VGPRs and spills
 // accumulators to pay for them (and every reload of a spilled address waits vmcnt(0), which
-// drains the LDS-DMA pipeline).  adr[half][h]: the lane's byte address in slot 0 / slot 4 (a
-// ds_read's immediate reaches 64 KiB, so one base per half of the 128 KiB).
+// drains the LDS-DMA pipeline).
 #define PG_DS_READ(dst, base, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(imm))
+// adr[h]: the lane's byte address in slot 0; slots 4-7 lie 64 KiB further on, past the reach of a ds_read's
+// immediate, and get their base from one v_add per k half made where it is used (kept as four more registers
+// for the whole kernel they were what pushed the fp8 form to 256 VGPRs and into scratch)
 template <int SLOT>
-__device__ __forceinline__ void pg_read_a(u32x4 (&fa)[4][2], const unsigned (&adr)[2][2]) {
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) PG_DS_READ(fa[mt][h], adr[SLOT >> 2][h], (SLOT & 3) * 16384 + mt * 2048);
+__device__ __forceinline__ unsigned pg_slot_base(unsigned adr0) {
+  if constexpr (SLOT < 4) return adr0;
+  unsigned a;
+  asm volatile("v_add_u32_e32 %0, 0x10000, %1" : "=v"(a) : "v"(adr0));
+  return a;
 }
 template <int SLOT>
-__device__ __forceinline__ void pg_read_b(u32x4 (&fb)[2][2], const unsigned (&adr)[2][2]) {
+__device__ __forceinline__ void pg_read_a(u32x4 (&fa)[4][2], const unsigned (&adr)[2]) {
+  const unsigned b0 = pg_slot_base<SLOT>(adr[0]), b1 = pg_slot_base<SLOT>(adr[1]);
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt)
+  for (int mt = 0; mt < 4; ++mt) {
+    PG_DS_READ(fa[mt][0], b0, (SLOT & 3) * 16384 + mt * 2048);
+    PG_DS_READ(fa[mt][1], b1, (SLOT & 3) * 16384 + mt * 2048);
+  }
+}
+template <int SLOT>
+__device__ __forceinline__ void pg_read_b(u32x4 (&fb)[2][2], const unsigned (&adr)[2]) {
+  const unsigned b0 = pg_slot_base<SLOT>(adr[0]), b1 = pg_slot_base<SLOT>(adr[1]);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) PG_DS_READ(fb[nt][h], adr[SLOT >> 2][h], (SLOT & 3) * 16384 + nt * 2048);
+  for (int nt = 0; nt < 2; ++nt) {
+    PG_DS_READ(fb[nt][0], b0, (SLOT & 3) * 16384 + nt * 2048);
+    PG_DS_READ(fb[nt][1], b1, (SLOT & 3) * 16384 + nt * 2048);
+  }
 }
 #undef PG_DS_READ
 // "the fragments are in": the wait names every register the asm reads filled, so that nothing
@@ -238,6 +253,7 @@ constexpr int PG_SIDE_CNT = PG_SIDE_QS + 2048;          // u32 [2][8]: candidate
 constexpr int PG_SIDE_KEY = PG_SIDE_CNT + 64;           // u32 [2][PG_PARK][2]: (score bits, code); wave w owns entries [w * PG_PARK / 8, ..)
 constexpr int PG_LDS_TOTAL = PG_SIDE_KEY + 2 * PG_PARK * 8;  // 153,664 bytes of the 163,840
 // a parked candidate's code: row inside the tile (8 bits) | query inside the tile << 8
+constexpr int PG_SPARSE_MAX = 8;   // survivors per wave and tile up to which the epilogue compares-and-branches per group of four registers
 constexpr int PG_FLUSH_KT = 2, PG_MIN_KT = 6;   // the flush brackets k-tiles 2 and 3 of the next tile
 
 // LDS accesses of the epilogue / flush: inline asm, so that hipcc neither orders them against the
@@ -309,13 +325,11 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
   }
   // ---- ... and of the reading side: LDS byte address of the lane's 16 bytes in slot 0 / slot 4
   // (pg_read_a / pg_read_b)
-  unsigned adrA[2][2], adrB[2][2];                   // [LDS half][k half h]
+  unsigned adrA[2], adrB[2];                         // [k half h]
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    adrA[0][h] = (unsigned)(((wr * 64 + r16) * 8 + ((4 * h + g) ^ tg_swz(r16))) * 16);
-    adrB[0][h] = (unsigned)(((wc * 32 + r16) * 8 + ((4 * h + g) ^ tg_swz(r16))) * 16);
-    adrA[1][h] = adrA[0][h] + 65536u;
-    adrB[1][h] = adrB[0][h] + 65536u;
+    adrA[h] = (unsigned)(((wr * 64 + r16) * 8 + ((4 * h + g) ^ tg_swz(r16))) * 16);
+    adrB[h] = (unsigned)(((wc * 32 + r16) * 8 + ((4 * h + g) ^ tg_swz(r16))) * 16);
   }
 
   auto tile_desc = [&](int j) __attribute__((always_inline)) {
@@ -365,7 +379,12 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
   // side data of tile `t` into copy `par`: every wave issues the same instructions (waves 4-7
   // repeat waves 0-3: same bytes to the same place), 256 bytes each
   auto stage_side = [&](const PgTile& t, int par) __attribute__((always_inline)) {
-    const int col = (wave & 3) * 64 + lane;
+    // (formed from an opaque copy of the thread id, per tile: computed once per kernel, `col * 4` and
+    //  `col * fthr_stride * 4` stay live across the k loop, and in the fp8 form -- 256 registers -- they were
+    //  spilled: each reload waits vmcnt(0), i.e. drains the LDS-DMA ring, twice per output tile)
+    int tid_s = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid_s));
+    const int col = tid_s & 255;   // = (wave & 3) * 64 + lane
     char* side = (char*)pg_lds;
     if constexpr (FUSE) {
       const int live = nq - t.q0 < PG_TILE ? nq - t.q0 : PG_TILE;
@@ -498,6 +517,7 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
   // issues one returning global atomic per candidate (slot in the query's list), step B -- four
   // k-tiles = 32 counted vmcnt waits later -- stores the keys
   uint32_t fslot[2] = {0u, 0u};
+  int last_wcount = PG_SPARSE_MAX + 1;   // survivors this wave parked in its previous tile (wave-uniform; the first tile takes the sweeps)
   int f_pp = 0, f_q0 = 0;     // wave-uniform
   int64_t f_row0 = 0;
   // (tid / lane copies behind an empty asm: what the flush and the epilogue derive from them is recomputed per
@@ -519,8 +539,10 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
       }
     }
   };
-  auto flush_b = [&](bool waited) __attribute__((always_inline)) {
-    if (!waited) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(fslot[0]), "+v"(fslot[1]) : "n"(PG_VMCNT) : "memory");
+  // drain == false: the caller guarantees that at least PG_VMCNT vector-memory instructions were issued after
+  // flush_a's atomics (see the invariant at the call site in the k loop); drain == true: wait for everything
+  auto flush_b = [&](bool drain) __attribute__((always_inline)) {
+    if (!drain) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(fslot[0]), "+v"(fslot[1]) : "n"(PG_VMCNT) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" : "+v"(fslot[0]), "+v"(fslot[1])::"memory");
     int tid = (int)threadIdx.x;
     asm volatile("" : "+v"(tid));
@@ -540,8 +562,9 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
   // ---- epilogue of one tile: scales (fp8), then scores out (materialised) or candidates parked
   auto epilogue = [&](const PgTile& t, int par) __attribute__((always_inline)) {
     const int wrow = wr * 128, wq = wc * 64;
-    int lane_e = (int)threadIdx.x & 63;
+    int lane_e = (int)threadIdx.x;   // (the copy is made opaque BEFORE the mask: `threadIdx.x & 63` itself was kept live -- and spilled in the fp8 form)
     asm volatile("" : "+v"(lane_e));
+    lane_e &= 63;
     const int lane = lane_e, r16 = lane_e & 15, g = lane_e >> 4;   // (shadow the kernel's: see flush_a)
     if constexpr (!FUSE) {
       // (rows / queries past the ends are not stored; fp8 scales are applied by tg_epilogue's own loads: this
@@ -560,23 +583,28 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
       const int lr0 = wrow + 4 * g;                                        // the lane's first row inside the tile
       const int lim = (int)(n - t.row0 < PG_TILE ? n - t.row0 : PG_TILE);  // live rows of this tile
       if constexpr (EB == 1) {   // per-row and per-query dequantisation scales, applied in place (as tg_epilogue: v * (rs * qs))
-        float qs[NT];
+        // two scores per instruction (v_pk_mul_f32: each half is an ordinary IEEE f32 product, so the bits are those of
+        // the scalar form): 128 instead of 256 multiplies per lane
+        f32x2_t qs[NT];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) qs[j] = pg_lds_read_f32(PG_SIDE_QS + par * 1024 + (wq + j * 16 + r16) * 4);
+        for (int j = 0; j < NT; ++j) {
+          const float q = pg_lds_read_f32(PG_SIDE_QS + par * 1024 + (wq + j * 16 + r16) * 4);
+          qs[j] = (f32x2_t){q, q};
+        }
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
           const f32x4_t rs = pg_lds_read_f32x4(PG_SIDE_RS + par * 1024 + (lr0 + i * 16) * 4);
+          const f32x2_t rs01 = {rs[0], rs[1]}, rs23 = {rs[2], rs[3]};
 #pragma unroll
-          for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              // (in place by construction: left to hipcc the 128 products go to new registers, the accumulator
-              //  quads stay live until their last element is read, and ~50 values spill)
-              float v = acc[i][j][r];
-              const float sc = rs[r] * qs[j];
-              asm volatile("v_mul_f32_e32 %0, %1, %0" : "+v"(v) : "v"(sc));
-              acc[i][j][r] = v;
-            }
+          for (int j = 0; j < NT; ++j) {
+            // (in place by construction: left to hipcc the 128 products go to new registers, the accumulator
+            //  quads stay live until their last element is read, and ~50 values spill)
+            f32x2_t lo = {acc[i][j][0], acc[i][j][1]}, hi = {acc[i][j][2], acc[i][j][3]};
+            const f32x2_t s01 = rs01 * qs[j], s23 = rs23 * qs[j];
+            asm volatile("v_pk_mul_f32 %0, %1, %0" : "+v"(lo) : "v"(s01));
+            asm volatile("v_pk_mul_f32 %0, %1, %0" : "+v"(hi) : "v"(s23));
+            acc[i][j] = (f32x4_t){lo[0], lo[1], hi[0], hi[1]};
+          }
         }
       }
       constexpr int WCAP = PG_PARK / 8;
@@ -620,26 +648,31 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
               if constexpr (!full)
                 mask[r] &= __ballot(lr0 + i * 16 + r < lim && lr0 + i * 16 + r > plo);
             }
+            // ONE scalar test per group of four registers (the no-survivor path then runs 4 compares, 3 s_or and
+            // a not-taken branch per group); with thresholds from a long prefix (configs[4]: 42 survivors per tile)
+            // nine groups in ten are empty
+            if (__builtin_expect((mask[0] | mask[1] | mask[2] | mask[3]) != 0, 0)) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              if (__builtin_expect(mask[r] != 0, 0)) {   // (unlikely: keeps the no-survivor path free of taken branches)
-                const bool hit = ((mask[r] >> lane) & 1ull) != 0;
-                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask[r] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask[r], 0u));
-                if (hit) {
-                  const int slot = wcount + rank;
-                  if (slot < WCAP) {   // (score bits, code): the order-preserving key is made at flush time
-                    pg_lds_write_u64(kadr + slot * 8, ((uint64_t)(cbase + (uint32_t)(i * 16 + r)) << 32) | __builtin_bit_cast(uint32_t, v[r]));
-                  } else {
-                    // the wave's eighth is full: this candidate goes straight to the query's global list (a
-                    // returning atomic and a store, and hipcc's vmcnt(0) behind the atomic drains the DMA
-                    // ring -- the price of a tile full of one query's neighbours, paid only there)
-                    uint32_t* hp = fstate_words + (int64_t)(t.q0 + ql) * fstate_stride;
-                    const uint32_t gs = __hip_atomic_fetch_add(hp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (gs < fcap)
-                      fcand[(int64_t)(t.q0 + ql) * fcap + gs] = ((uint64_t)score_key(v[r]) << 32) | (uint32_t)(pairs.row_base + t.row0 + lr0 + i * 16 + r);
+              for (int r = 0; r < 4; ++r) {
+                if (mask[r] != 0) {
+                  const bool hit = ((mask[r] >> lane) & 1ull) != 0;
+                  const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask[r] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask[r], 0u));
+                  if (hit) {
+                    const int slot = wcount + rank;
+                    if (slot < WCAP) {   // (score bits, code): the order-preserving key is made at flush time
+                      pg_lds_write_u64(kadr + slot * 8, ((uint64_t)(cbase + (uint32_t)(i * 16 + r)) << 32) | __builtin_bit_cast(uint32_t, v[r]));
+                    } else {
+                      // the wave's eighth is full: this candidate goes straight to the query's global list (a
+                      // returning atomic and a store, and hipcc's vmcnt(0) behind the atomic drains the DMA
+                      // ring -- the price of a tile full of one query's neighbours, paid only there)
+                      uint32_t* hp = fstate_words + (int64_t)(t.q0 + ql) * fstate_stride;
+                      const uint32_t gs = __hip_atomic_fetch_add(hp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                      if (gs < fcap)
+                        fcand[(int64_t)(t.q0 + ql) * fcap + gs] = ((uint64_t)score_key(v[r]) << 32) | (uint32_t)(pairs.row_base + t.row0 + lr0 + i * 16 + r);
+                    }
                   }
+                  wcount += __builtin_popcountll(mask[r]);
                 }
-                wcount += __builtin_popcountll(mask[r]);
               }
             }
           }
@@ -653,7 +686,7 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
       // slots in the wave's eighth, (3) a second sweep parks them: v_cmpx makes the survivors the
       // active lanes, they store (score, code) and step their address, exec is restored -- five
       // instructions per register, the same whatever survives.
-      auto sweep = [&]() __attribute__((always_inline)) {
+      auto sweep = [&]() __attribute__((always_inline)) -> bool {   // true: more survivors than the wave's eighth holds, nothing parked
         float thr[NT];
         uint32_t base[NT];
 #pragma unroll
@@ -681,36 +714,41 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
         x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
         x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
         int total = __builtin_amdgcn_readlane((int)x, 63);
-        if (__builtin_expect(total > WCAP, 0)) {
-          // more than the wave's eighth holds (rows ordered by topic: a tile full of one query's neighbours):
-          // the register-by-register path parks what fits and gives the fused path up for exactly the
-          // queries whose candidates did not
-          pass(std::true_type{}, std::true_type{});
-        } else {
-          wcount = total;
-          if (total != 0) {
-            unsigned ak = kadr + (x - cnt) * 8;   // the lane's first slot
-            // (the code is computed INSIDE the asm, from a literal: handed in as an operand, hipcc computes all 128
-            //  codes ahead, spills them, and reloads each behind a vmcnt(0) that drains the LDS-DMA ring)
-            pg_static_for<NT>([&](auto J) {
-              pg_static_for<MT>([&](auto I) {
-                pg_static_for<4>([&](auto R) {
-                  constexpr int j = decltype(J)::value, i = decltype(I)::value, r = decltype(R)::value;
-                  pg_park_if<i * 16 + r>(ak, val(i, j, r), thr[j], base[j]);
-                });
+        // more than the wave's eighth holds (rows ordered by topic: a tile full of one query's neighbours): the
+        // register-by-register path (the caller's) parks what fits and sends the rest to the global lists
+        if (__builtin_expect(total > WCAP, 0)) return true;
+        wcount = total;
+        if (total != 0) {
+          unsigned ak = kadr + (x - cnt) * 8;   // the lane's first slot
+          // (the code is computed INSIDE the asm, from a literal: handed in as an operand, hipcc computes all 128
+          //  codes ahead, spills them, and reloads each behind a vmcnt(0) that drains the LDS-DMA ring)
+          pg_static_for<NT>([&](auto J) {
+            pg_static_for<MT>([&](auto I) {
+              pg_static_for<4>([&](auto R) {
+                constexpr int j = decltype(J)::value, i = decltype(I)::value, r = decltype(R)::value;
+                pg_park_if<i * 16 + r>(ak, val(i, j, r), thr[j], base[j]);
               });
             });
-          }
+          });
         }
+        return false;
       };
       // pair mode: tiles wholly above the diagonal are ordinary tiles, tiles wholly on or below it hold nothing,
       // the few that straddle it (or hold queries of the previous chunk) take the masked path
       const long long prow0 = pairs.row_base + t.row0, pq0 = pairs.query_row0 + t.q0;
       const bool pair_plain = !pairs.on || (prow0 > pq0 + PG_TILE - 1 && pq0 >= pairs.first_query);
       const bool pair_empty = pairs.on && prow0 + PG_TILE - 1 <= pq0;
+      // Interior tiles take the two branch-free sweeps when the wave's last tile held many survivors (configs[2]:
+      // ~50 per wave and tile, a third of the registers hold one) and the grouped compare-and-branch path when it
+      // held few (configs[4], thresholds from a 156 k-row prefix: ~5 per wave and tile -- the sweeps' 7 vector
+      // instructions per register against 1 + a scalar test per four).  Either is exact whatever survives.
       if (pair_empty) wcount = 0;
-      else if (lim == PG_TILE && t.q0 + PG_TILE <= nq && pair_plain && EXP != 31) sweep();
-      else pass(std::false_type{}, std::false_type{});   // (EXP 31: the branchy path everywhere, A/B)
+      else if (lim == PG_TILE && t.q0 + PG_TILE <= nq && pair_plain && EXP != 31) {
+        bool grouped = last_wcount <= PG_SPARSE_MAX;
+        if (!grouped) grouped = sweep();
+        if (grouped) pass(std::true_type{}, std::true_type{});
+      } else pass(std::false_type{}, std::false_type{});   // (EXP 31: the branchy path everywhere, A/B)
+      last_wcount = EXP == 32 ? PG_SPARSE_MAX + 1 : wcount;   // (EXP 32: the sweeps on every interior tile, A/B)
       if (lane == 0) pg_lds_write_u32(PG_SIDE_CNT + (par * 8 + wave) * 4, (uint32_t)(wcount < WCAP ? wcount : WCAP));
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // parked entries written before this wave's next barrier
     }
@@ -735,6 +773,7 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
   // keeping the accumulators in place across the join of the two bodies.)
   unsigned long long loop_t0 = 0, loop_t1 = 0, loop_cycles = 0;   // (PG_CLOCKS builds: cycles inside the k loops)
   unsigned long long epi_t0 = 0, epi_t1 = 0, epi_cycles = 0;      // (... and inside the epilogues)
+  (void)loop_cycles; (void)epi_cycles;
   for (int T = 0; T < my_tiles; ++T) {
 #ifdef PG_TRACE
     tracing = blockIdx.x == PG_TRACE_BLOCK && T == PG_TRACE_TILE;
@@ -747,14 +786,29 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
       for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     PG_LOOP_CLOCK(loop_t0);
     for (int kt = 0; kt < KT - 2; kt += 2) {
-      // the previous tile's candidates: atomics out before this pair of k-tiles, slots used after it
-      // (eight phases = sixteen younger DMA instructions later: every counted wait since covers them);
-      // the returned slots live in registers only across this straight-line stretch
+      // The previous tile's candidates: atomics out before this pair of k-tiles (flush_a), slots used after it
+      // (flush_b); the returned slots live in registers only across this straight-line stretch.
+      // INVARIANT (what the counted wait in flush_b rests on).  flush_a's returning atomics are issued by inline asm,
+      // so hipcc inserts no wait for them; they sit in the wave's in-order vmcnt queue like any load.  Between
+      // flush_a and flush_b the wave issues the LDS-DMA pieces of two k-tiles: 2 k-tiles x 4 phases x 2 pieces =
+      // PG_FLUSH_YOUNGER = 16 vector-memory instructions, all YOUNGER than the atomics.  `s_waitcnt vmcnt(PG_VMCNT)`
+      // retires everything but the PG_VMCNT youngest, so it covers the atomics iff PG_FLUSH_YOUNGER >= PG_VMCNT.
+      // A build that issues no DMA in the loop (ablations 1 and 26: kStage false) or forces a larger count
+      // (PG_VMCNT_FORCE) does not have that cover and must wait vmcnt(0) instead: round 2's "no LDS-DMA in loop"
+      // ablation waited the counted form, the slots landed after hipcc had reused fslot[]'s registers, and the
+      // candidate store went through a corrupted address -- the GPU memory fault of gpurun_out/pb8.log.
+      // The flush needs loop iteration kt == PG_FLUSH_KT to exist in THIS loop (not in the two tail k-tiles):
+      // PG_FLUSH_KT + 2 <= PG_MIN_KT - 2, and the host (phased_ok) refuses rows shorter than PG_MIN_KT k-tiles.
+      constexpr int PG_FLUSH_YOUNGER = 2 * 4 * 2;
+      constexpr bool kFlushCovered = kStage && PG_FLUSH_YOUNGER >= PG_VMCNT;
+      static_assert(EXP != 0 && EXP != 20 && EXP != 30 && EXP != 31 && EXP != 32 ? true : kFlushCovered,
+                    "shipped forms: the counted wait in flush_b must cover flush_a's atomics");
+      static_assert(PG_FLUSH_KT % 2 == 0 && PG_FLUSH_KT + 2 <= PG_MIN_KT - 2, "the flush iteration must lie inside the main k loop");
       const bool flush = FUSE && T > 0 && kt == PG_FLUSH_KT;
       if (flush) flush_a();
       ktile(PG_C(0), PG_C(0), kt);
       ktile(PG_C(1), PG_C(0), kt + 1);
-      if (flush) flush_b(EXP == 1);
+      if (flush) flush_b(!kFlushCovered);
     }
     ktile(PG_C(0), PG_C(1), KT - 2);
     ktile(PG_C(1), PG_C(2), KT - 1);

@@ -25,6 +25,9 @@ pytestmark = pytest.mark.gpu
     ("fp8", 140000, 3072, 256, 100),   # configs[4]'s row length
     ("fp8", 10000, 256, 130, 20),      # 2 k-tiles per row
     ("fp8", 135000, 1536, 513, 64),    # three query tiles, the last with one query
+    # few survivors per tile (small k): the epilogue's grouped compare-and-branch path (PG_SPARSE_MAX)
+    ("f16", 140000, 1536, 300, 8),
+    ("fp8", 140000, 3072, 256, 5),
 ])
 def test_phased_equals_round1_kernel_and_oracle(gpu, dtype, n, d, nq, k):
     from svs_amd import DeviceIndex

@@ -114,12 +114,18 @@ int run(int64_t n, int d, int nq, int rounds) {
   CK(hipDeviceSynchronize());
   typedef void (*Fn)(const Args&, int);
   struct V { const char* name; Fn fn; };
+#ifdef PGB_FULL   // every ablation (slow to compile: fourteen instantiations per operand type)
   const V vs[] = {{"round-1 tiled 256x256", launch_tiled<EB>}, {"phased", launch_phased<EB, 0>}, {"phased, no LDS-DMA in loop", launch_phased<EB, 1>},
                   {"phased, no fragment reads", launch_phased<EB, 2>}, {"phased, no MFMA", launch_phased<EB, 3>},
                   {"phased, no stagger", launch_phased<EB, 7>}, {"phased, LDS-DMA + barriers only", launch_phased<EB, 5>}, {"phased, DMA pieces between the MFMAs", launch_phased<EB, 30>}, {"phased, always k-tile 0 (L2 hits)", launch_phased<EB, 21>}, {"phased, DMA + barriers only, always k-tile 0", launch_phased<EB, 25>}, {"phased, barriers only", launch_phased<EB, 26>}, {"phased, epilogue with a branch per register", launch_phased<EB, 31>}, {"phased, corpus pieces nontemporal", launch_phased<EB, 20>}, {"phased, no epilogue", launch_phased<EB, 14>}};
+#else             // round 3's working set
+  const V vs[] = {{"round-1 tiled 256x256", launch_tiled<EB>}, {"phased", launch_phased<EB, 0>}, {"phased, corpus pieces nontemporal", launch_phased<EB, 20>},
+                  {"phased, two-sweep epilogue on every tile", launch_phased<EB, 32>}, {"phased, no epilogue", launch_phased<EB, 14>},
+                  {"phased, LDS-DMA + barriers only", launch_phased<EB, 5>}};
+#endif
   const int NVALL = sizeof(vs) / sizeof(vs[0]);
   const char* only = getenv("PGB_ONLY");          // e.g. PGB_ONLY=2 runs variant 2 alone (fault hunting)
-  V sel[16]; int NV = 0;
+  V sel[20]; int NV = 0;
   for (int v = 0; v < NVALL; ++v) if (!only || atoi(only) == v) sel[NV++] = vs[v];
 #define vs sel
   std::vector<std::vector<float>> ms(NV);
@@ -169,5 +175,11 @@ int main(int argc, char** argv) {
   const int64_t n = argc > 1 ? atoll(argv[1]) : 1000000;
   const int d = argc > 2 ? atoi(argv[2]) : 1536, nq = argc > 3 ? atoi(argv[3]) : 1024, eb = argc > 4 ? atoi(argv[4]) : 2;
   const int rounds = argc > 5 ? atoi(argv[5]) : 3;
+#if defined(PGB_EB) && PGB_EB == 1
+  return run<1>(n, d, nq, rounds);
+#elif defined(PGB_EB) && PGB_EB == 2
+  return run<2>(n, d, nq, rounds);
+#else
   return eb == 2 ? run<2>(n, d, nq, rounds) : run<1>(n, d, nq, rounds);
+#endif
 }
