@@ -81,13 +81,83 @@ def batched_config(torch, idx, name, n, d, dtype, nq, k, seed, reps):
                 hit = [v["hbm_read_bytes_per_launch"] for kn, v in pm.items() if "gemm_phased_kernel<true" in kn and "hbm_read_bytes_per_launch" in v]
                 if hit:
                     out["roofline"]["traffic"] = hit[0]
-                    out["roofline"]["traffic_source"] = os.path.relpath(f, ROOT) + " (FETCH_SIZE x 2, reads only)"
+                    out["roofline"]["traffic_source"] = os.path.relpath(f, ROOT) + " (FETCH_SIZE x 2, reads only; profile taken at git %s)" % json.load(open(f)).get("git_head", "unrecorded")
                     break
             except Exception:
                 pass
     if dtype == "fp8":   # mixed bound, both fractions
         out["roofline_hbm"] = {"bound": "hbm", "achieved": bytes_ / (dom_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                                "frac": bytes_ / (dom_ms * 1e-3) / HBM_PEAK, "algorithmic_bytes_per_launch": bytes_}
+    return out
+
+
+def kb_figures(seed, k, retrieve_rows=10_548, cold_rows=100_000, d=1536, iters=200):
+    """Secondary figures (N = 1; not `value`): the path of reference src/svs/kb.py:1608-1640 end to end through the
+    KB mirror (svs_amd.KB: embed lookup -> HIP search -> SQLite fetch of k docs) on an on-disk KB of BASELINE.json
+    configs[0]'s size, and the cold start (SQLite file -> first result, reference kb.py:573-618: 98.7 s at 1M rows,
+    BASELINE.md) on a `cold_rows`-row KB.  Synthetic unit-norm Gaussian vectors; queries are texts whose vectors
+    the embedding function looks up."""
+    import shutil
+    import tempfile
+    import svs_amd
+    from svs_amd.kb import _Store
+
+    def write_kb(path, n, rng):
+        st = _Store(path)
+        with st.transaction():
+            for b0 in range(0, n, 20000):
+                x = rng.standard_normal((min(20000, n - b0), d)).astype(np.float32)
+                x /= np.linalg.norm(x, axis=1, keepdims=True)
+                st.conn.executemany("INSERT INTO embeddings (embedding) VALUES (?)", [(r.tobytes(),) for r in x])
+                st.conn.executemany("INSERT INTO docs (parent_id, level, text, embedding, meta) VALUES (NULL, 0, ?, ?, NULL)",
+                                    [(f"doc {b0 + i}", b0 + i + 1) for i in range(len(x))])
+        st.close()
+
+    rng = np.random.default_rng(seed)
+    qv = rng.standard_normal((iters + 8, d))
+    qv = (qv / np.linalg.norm(qv, axis=1, keepdims=True)).astype(np.float32)
+    lookup = {f"query {i}": qv[i].tolist() for i in range(len(qv))}
+
+    async def ef(texts):
+        return [lookup[t] for t in texts]
+
+    td = tempfile.mkdtemp(prefix="svs_bench_kb_")
+    out = {}
+    try:
+        p1 = os.path.join(td, "retrieve.sqlite")
+        write_kb(p1, retrieve_rows, rng)
+        kb = svs_amd.KB(p1, ef)
+        kb.load()
+        for i in range(iters, iters + 8):
+            kb.retrieve(f"query {i}", k)
+        lats = []
+        for i in range(iters):
+            a = time.perf_counter()
+            res = kb.retrieve(f"query {i}", k)
+            lats.append((time.perf_counter() - a) * 1e3)
+        assert len(res) == min(k, retrieve_rows)
+        kb.close()
+        out["kb_retrieve_p50_ms"] = float(np.median(lats))
+        out["kb_retrieve"] = {"rows": retrieve_rows, "dim": d, "k": k, "queries": iters, "min_ms": float(min(lats)),
+                              "what": "svs_amd.KB.retrieve() on an on-disk KB: embed lookup + HIP search + SQLite fetch of k docs "
+                                      "(the reference publishes 11 ms on a 10,548-doc KB, README.md:128-129)"}
+        p2 = os.path.join(td, "cold.sqlite")
+        write_kb(p2, cold_rows, rng)
+        os.system("sync")
+        a = time.perf_counter()
+        kb = svs_amd.KB(p2, ef)
+        res = kb.retrieve("query 0", k)
+        cold = time.perf_counter() - a
+        a = time.perf_counter()
+        kb.retrieve("query 1", k)
+        warm = time.perf_counter() - a
+        kb.close()
+        out["cold_start_s"] = cold
+        out["cold_start"] = {"rows": cold_rows, "dim": d, "file_gb": os.path.getsize(p2) / 1e9, "next_retrieve_ms": warm * 1e3,
+                             "what": "open an on-disk KB -> first retrieve() result (BLOBs -> pinned staging blocks -> HBM, "
+                                     "svs_index_staging_*); the reference's first query at 1M rows takes 98.7 s (BASELINE.md)"}
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
     return out
 
 
@@ -136,6 +206,9 @@ def main():
     ap.add_argument("--configs", default="2,4",
                     help="BASELINE.json batch configs measured as secondary figures at N = 1 (2: 1M x 1536 f16 x 1024 "
                          "queries; 4: 10M x 3072 fp8 x 256 queries; empty: skip)")
+    ap.add_argument("--kb", type=int, default=1,
+                    help="1: also time KB.retrieve() end to end on a 10,548-row on-disk KB and the cold start of a "
+                         "100,000-row one (N = 1 only; 0: skip)")
     ap.add_argument("--inflight", type=int, default=1,
                     help="searches kept in flight on separate HIP streams (2 lets the top-k "
                          "stage of query i overlap the score stage of query i+1)")
@@ -266,16 +339,23 @@ def main():
         whole.release()
         sharded_check = {"queries": min(16, K), "mismatches": bad}
 
-    # ---- p50 latency at the C-ABI boundary (host buffers in, results out, synced)
-    lat_ms = None
+    # ---- p50 latency at the C-ABI boundary (host buffers in, results out, synced): its own
+    # latency_iters (>= 200) distinct queries, whatever --steps / --warmup were
+    lat_ms, lat_n = None, 0
     if world == 1:
-        qh = queries[: min(args.latency_iters, K + W)].cpu().numpy()
+        gl = torch.Generator(device=dev)
+        gl.manual_seed(args.seed + 555)
+        ql = torch.randn((max(args.latency_iters, 200) + 5, d), device=dev, dtype=torch.float32, generator=gl)
+        qh = (ql / ql.norm(dim=1, keepdim=True)).cpu().numpy()
+        del ql
+        for q in qh[:5]:
+            idx.search(q, k)
         lats = []
-        for q in qh:
+        for q in qh[5:]:
             a = time.perf_counter()
             idx.search(q, k)
             lats.append((time.perf_counter() - a) * 1e3)
-        lat_ms = float(np.median(lats))
+        lat_ms, lat_n = float(np.median(lats)), len(lats)
 
     # HBM traffic of the dominant kernel from the committed PMC passes (separate
     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950
@@ -289,7 +369,8 @@ def main():
                 pm = json.load(open(f))["pmc"]
                 kn = [v for kname, v in pm.items() if "gemv_f32" in kname and "hbm_bytes_per_launch" in v]
                 if kn:
-                    traffic, traffic_src = kn[0]["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
+                    traffic = kn[0]["hbm_bytes_per_launch"]
+                    traffic_src = os.path.relpath(f, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; profile taken at git %s)" % json.load(open(f)).get("git_head", "unrecorded")
                     break
             except Exception:
                 continue
@@ -389,6 +470,10 @@ def main():
         i4.release()
         torch.cuda.empty_cache()
 
+    kb_out = {}
+    if world == 1 and args.kb and args.dtype == "f32":
+        kb_out = kb_figures(args.seed + 31, k)
+
     out = None
     if rank == 0:
         kernel_ms = score_ms / max(launches, 1)
@@ -418,6 +503,10 @@ def main():
                 "steps_per_exchange": G if (world > 1 or force_dist) else None,
             },
             "p50_latency_ms": lat_ms,
+            "p50_latency_queries": lat_n,
+            "kb_retrieve_p50_ms": kb_out.get("kb_retrieve_p50_ms"),
+            "cold_start_s": kb_out.get("cold_start_s"),
+            "kb": {k_: v for k_, v in kb_out.items() if k_ in ("kb_retrieve", "cold_start")} or None,
             "sharded_check": sharded_check,
             "batched": batched,
             "concurrent": concurrent,
@@ -460,19 +549,25 @@ def main():
             if [int(x) for x in got_r] != [i for _, i in exp] or \
                     max(abs(float(a) - b) for a, (b, _) in zip(got_s, exp)) > 1e-5:
                 mism += 1
+        blas = "threadpoolctl unavailable"
         try:
             import threadpoolctl
-            thr = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [1])
+            info = threadpoolctl.threadpool_info()
+            thr = max([p.get("num_threads", 1) for p in info] or [1])
+            blas = "; ".join("%s %s (%s, %s threads)" % (p.get("internal_api"), p.get("version"), p.get("threading_layer", "-"), p.get("num_threads"))
+                             for p in info if p.get("user_api") == "blas") or "no BLAS pool reported"
         except Exception:
             thr = os.cpu_count()
+        blas += "; OPENBLAS_NUM_THREADS=%s OMP_NUM_THREADS=%s, os.cpu_count()=%s" % (
+            os.environ.get("OPENBLAS_NUM_THREADS", "unset"), os.environ.get("OMP_NUM_THREADS", "unset"), os.cpu_count())
         try:
             thr = min(int(thr), len(os.sched_getaffinity(0)))
         except Exception:
             pass
         out["cpu_baseline"] = {
             "value": 1.0 / p50, "unit": "queries/s", "cores": int(thr), "kind": "port",
-            "sample": "full %dx%d corpus, %d queries after 3 warm-ups, numpy %s np.dot + argpartition + sort (oracle/svs_oracle.py); p50 %.2f ms, min %.2f ms"
-                      % (n_total, d, len(ts), np.__version__, p50 * 1e3, min(ts) * 1e3),
+            "sample": "full %dx%d corpus, %d queries after 3 warm-ups, numpy %s np.dot + argpartition + sort (oracle/svs_oracle.py); p50 %.2f ms, min %.2f ms; BLAS: %s"
+                      % (n_total, d, len(ts), np.__version__, p50 * 1e3, min(ts) * 1e3, blas),
         }
         out["parity_spot_check"] = {"queries": min(8, K), "mismatches": mism}
 

@@ -171,11 +171,20 @@ int32_t svs_index_search(svs_index* idx, const float* queries, int32_t nq, int32
  * an executor thread outside the KB lock (src/svs/kb.py:1184-1190), so a server has many threads inside the
  * search at once; with enable != 0, svs_index_search calls with nq == 1 that arrive while the device is busy
  * are queued and answered TOGETHER by one batched pass over the corpus when it is free (up to 256; a call that
- * finds the device idle runs at once, alone).  Rows and their order are those of the solo search; scores can
- * differ from the single-query kernels' in the last bits (another summation order).  Errors stay with the call
- * that made them.  svs_index_coalesce_stats: passes made / queries answered through this path. */
+ * finds the device idle runs at once, alone).  The answer is the SAME total order (score desc, row desc,
+ * src/svs/util.py:203) applied to scores that can differ from the single-query kernels' in the last bits
+ * (the batched kernels sum in another order, far inside 1e-5): two rows whose scores are closer than that
+ * rounding noise may therefore come out swapped, exactly as between two runs of numpy's own sgemv with
+ * different blocking (hard part 1).  On every golden corpus recorded from the reference the
+ * coalesced rows equal the reference's position by position (tests/test_coalesce.py).  Errors stay with the
+ * call that made them.  svs_index_coalesce_stats: passes made / queries answered through this path;
+ * svs_index_coalesce_sizes: out[s] = passes that carried exactly s queries, s < cap (cap <= 257). */
 int32_t svs_index_set_coalesce(svs_index* idx, int32_t enable);
 int32_t svs_index_coalesce_stats(svs_index* idx, int64_t* passes, int64_t* queries);
+int32_t svs_index_coalesce_sizes(svs_index* idx, int64_t* out, int32_t cap);
+/* Tests and benchmarks: the NEXT coalesced pass waits (at most 5 s) until n single-query calls are queued,
+ * so that a pass of a chosen size can be formed on purpose; one shot, 0 cancels. */
+int32_t svs_index_coalesce_hold(svs_index* idx, int32_t n);
 
 /* Device-resident variant for pipelines and the multi-GPU gather (8(e)): queries
  * and outputs are device pointers on the index's device, work is enqueued on

@@ -64,6 +64,8 @@ SIGNATURES = {
     "svs_index_staging_finish": (C.c_int32, [_P]),
     "svs_index_set_coalesce": (C.c_int32, [_P, C.c_int32]),
     "svs_index_coalesce_stats": (C.c_int32, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "svs_index_coalesce_sizes": (C.c_int32, [_P, C.POINTER(C.c_int64), C.c_int32]),
+    "svs_index_coalesce_hold": (C.c_int32, [_P, C.c_int32]),
     "svs_multi_create": (C.c_int32, [_P, C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.POINTER(_P)]),
     "svs_multi_search": (C.c_int32, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.POINTER(C.c_int32)]),
     "svs_multi_retain": (C.c_int32, [_P]),

@@ -10,9 +10,11 @@ while another is in flight are queued and go out TOGETHER as one ``search_batch`
 free.  Nothing waits for company: a search that finds the device idle runs at once, alone, through
 the single-query kernels exactly as without this class.
 
-Results: the rows are those of the solo search, in the same order (one total order, the batched
-kernels are parity-tested against the same oracle); scores can differ from the solo kernels' in the
-last bits (another summation order), far inside the 1e-5 the reference's own BLAS leaves open.
+Results: the same total order (score desc, row desc) applied to scores that can differ from the solo
+kernels' in the last bits (the batched kernels sum in another order, far inside the 1e-5 the
+reference's own BLAS leaves open); rows closer than that rounding noise could swap.  On every golden
+corpus recorded from the reference the coalesced rows equal the reference's position by position
+(tests/test_search_gpu.py::test_search_golden).
 """
 from __future__ import annotations
 

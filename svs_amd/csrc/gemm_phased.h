@@ -318,10 +318,11 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
   // range check does not see soffset -- so each piece adds its scalar to the base just before it is issued
   // (pg_voff: one v_add, volatile so that hipcc does not hoist the eight sums back into eight live registers).
   const unsigned wave_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)pg_lds + (unsigned)wave * 1024u;   // LDS byte address of the wave's 1 KiB in slot 0
-  int vbase;
+  int vbase, vbase_tm = 0;
   {
     const int li0 = 8 * wave + (lane >> 3), pc = lane & 7;
     vbase = li0 * ldb + (pc ^ tg_swz(li0)) * 16;
+    if constexpr (EXP == 40 || EXP == 45) vbase_tm = li0 * TG_BKB + (pc ^ tg_swz(li0)) * 16;
   }
   // ---- ... and of the reading side: LDS byte address of the lane's 16 bytes in slot 0 / slot 4
   // (pg_read_a / pg_read_b)
@@ -362,12 +363,13 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
   auto stage_piece = [&](auto KIND, auto SLOT, auto NEXT, int kt, auto JJ) __attribute__((always_inline)) {
     constexpr int kind = decltype(KIND)::value, slot = decltype(SLOT)::value, jj = decltype(JJ)::value;
     constexpr bool next = decltype(NEXT)::value != 0;
-    const int soff = (EXP == 21 || EXP == 25) ? 0 : kt * TG_BKB;   // (ablation 21: always the first k-tile: L2 hits)
+    constexpr bool tm = (EXP == 40 || EXP == 45) && (kind & 1);   // (timing-only: the corpus addressed as if tile-major -- a k-tile of a row tile one contiguous 32 KiB block)
+    const int soff = (EXP == 21 || EXP == 25) ? 0 : (tm ? kt * (PG_TILE * TG_BKB) : kt * TG_BKB);   // (ablation 21: always the first k-tile: L2 hits)
     const __amdgpu_buffer_rsrc_t rs = (kind & 1) ? (next ? nxt.a : cur.a) : (next ? nxt.b : cur.b);
     const int rows = (kind & 1) ? jj * 128 + (kind >> 1) * 64 : wr * 32 + jj * 128 + (kind >> 1) * 32;
-    const int vo = pg_voff(vbase, rows * ldb);
+    const int vo = tm ? pg_voff(vbase_tm, rows * TG_BKB) : pg_voff(vbase, rows * ldb);
     const unsigned dst = pg_lds_dest<slot * PG_SLOT * 16 + jj * 8192>(wave_lds);
-    if constexpr (EXP == 20 && (kind & 1))   // (corpus rows nontemporal: the single-query-tile form, see launch_tiled_eb)
+    if constexpr ((EXP == 20 || EXP == 40 || EXP == 45) && (kind & 1))   // (corpus rows nontemporal: the single-query-tile form, see launch_tiled_eb)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(uintptr_t)dst, 16, vo, soff, 0, 2);
     else
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(uintptr_t)dst, 16, vo, soff, 0, 0);
@@ -405,7 +407,7 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
 
   f32x4_t acc[MT][NT];
   u32x4 fa[4][2], fb0[2][2], fb1[2][2];
-  if constexpr (EXP == 2 || EXP == 5 || EXP == 25 || EXP == 26) {   // (ablation without fragment reads: defined operands)
+  if constexpr (EXP == 2 || EXP == 5 || EXP == 25 || EXP == 26 || EXP == 45) {   // (ablation without fragment reads: defined operands)
     const u32x4 c = {0x3c003c00u + (uint32_t)lane, 0x3c003c00u, 0x38003800u, 0x3c003c00u};
 #pragma unroll
     for (int i = 0; i < 4; ++i) fa[i][0] = fa[i][1] = c;
@@ -456,7 +458,7 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
     }
   };
 #define PG_C(v) std::integral_constant<int, (v)>{}
-  constexpr bool kStage = EXP != 1 && EXP != 26, kRead = EXP != 2 && EXP != 5 && EXP != 25 && EXP != 26, kMma = EXP != 3 && EXP != 5 && EXP != 25 && EXP != 26;   // (26: barriers only)   // (EXP 5: LDS-DMA and barriers only)
+  constexpr bool kStage = EXP != 1 && EXP != 26, kRead = EXP != 2 && EXP != 5 && EXP != 25 && EXP != 26 && EXP != 45, kMma = EXP != 3 && EXP != 5 && EXP != 25 && EXP != 26 && EXP != 45;   // (45: tile-major corpus, DMA + barriers only)   // (26: barriers only)   // (EXP 5: LDS-DMA and barriers only)
   constexpr bool kDmaInMma = (PG_DMA_IN_MMA != 0) != (EXP == 30);   // (EXP 30: the other placement, A/B)
   // what follows the loads of a phase: [retire the B reads] wait for the NEXT phase's data, barrier,
   // fragments in, 16 MFMAs at raised priority (keeps hipcc from moving them over the barriers), barrier
@@ -801,8 +803,10 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
       // PG_FLUSH_KT + 2 <= PG_MIN_KT - 2, and the host (phased_ok) refuses rows shorter than PG_MIN_KT k-tiles.
       constexpr int PG_FLUSH_YOUNGER = 2 * 4 * 2;
       constexpr bool kFlushCovered = kStage && PG_FLUSH_YOUNGER >= PG_VMCNT;
+#ifndef PG_VMCNT_FORCE
       static_assert(EXP != 0 && EXP != 20 && EXP != 30 && EXP != 31 && EXP != 32 ? true : kFlushCovered,
                     "shipped forms: the counted wait in flush_b must cover flush_a's atomics");
+#endif
       static_assert(PG_FLUSH_KT % 2 == 0 && PG_FLUSH_KT + 2 <= PG_MIN_KT - 2, "the flush iteration must lie inside the main k loop");
       const bool flush = FUSE && T > 0 && kt == PG_FLUSH_KT;
       if (flush) flush_a();

@@ -218,7 +218,7 @@ static int32_t multi_search_impl(svs_multi* m, const float* queries, int32_t nq,
   if (live.empty() || d != m->d || nq < 0 || (nq > 0 && !queries))
     return svs_index_search(m->shards[0], queries, nq, d, k, out_scores, out_rows, out_count);
   const int kk = std::max(k, 0);
-  const int count = (int)std::min<int64_t>(kk, rows - dead);
+  int count = (int)std::min<int64_t>(kk, rows - dead);
   if (out_count) *out_count = count;
   if (nq == 0 || count == 0) return SVS_OK;
   if (!out_scores || !out_rows) return refail(SVS_ERR_INVALID, "null output");
@@ -255,6 +255,17 @@ static int32_t multi_search_impl(svs_multi* m, const float* queries, int32_t nq,
   latch->wait();
   for (int t = 0; t < L; ++t)
     if (part[t].rc != SVS_OK) return refail(part[t].rc, "shard " + std::to_string(live[t]) + ": " + part[t].msg);
+  // The snapshot above was taken without a lock: a concurrent svs_index_mask_rows on a shard handle
+  // (svs_multi_shard) can have shrunk a shard since.  What the shards RETURNED is what there is -- one index
+  // under the same interleaving answers min(k, live rows at the time of its search) too.
+  {
+    int64_t got = 0;
+    for (int t = 0; t < L; ++t) got += part[t].cnt;
+    if (got < count) {
+      count = (int)got;
+      if (out_count) *out_count = count;
+    }
+  }
   // L sorted lists per query -> the best `count` under (score key desc, row desc)
   std::vector<int> head((size_t)L);
   for (int qi = 0; qi < nq; ++qi) {

@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
@@ -135,6 +136,9 @@ struct svs_index {
   };
   std::atomic<bool> coalesce{false};
   std::atomic<bool> co_round{true};
+  std::atomic<int64_t> co_sizes[257] = {};   // co_sizes[s]: passes that carried s queries
+  int co_hold = 0;                           // svs_index_coalesce_hold: the next pass waits for this many queued callers (under co_mu)
+  std::condition_variable co_hold_cv;
   std::mutex co_mu;
   std::vector<Waiter*> co_pending;
   bool co_busy = false;
@@ -202,6 +206,16 @@ void index_destroy(svs_index* idx) {
   (void)hipFree(idx->dead_dev);
   (void)hipFree(idx->dead_bits_dev);
   delete idx;
+}
+
+// svs_index_staging_commit publishes idx->n while its H2D copy and conversion are still queued on the staging
+// stream: EVERY entry point that reads idx->rows (searches, scores, pairwise, debug read-back) waits here first.
+int staging_wait(svs_index* idx) {
+  if (!idx->staging_pending.load()) return SVS_OK;
+  std::lock_guard<std::mutex> lk(idx->stg_mu);
+  if (idx->stg.st) HIP_TRY(hipStreamSynchronize(idx->stg.st));
+  idx->staging_pending.store(false);
+  return SVS_OK;
 }
 
 // `want`: the stream the caller will enqueue on (nullptr = the context's own).
@@ -814,11 +828,7 @@ int enqueue_search(svs_index* idx, Ctx* c, const float* q_dev, int nq, int k, in
                    float* out_s, int64_t* out_r, hipStream_t st, bool allow_fused = false) {
   const int64_t n = idx->n;
   int rc;
-  if (idx->staging_pending.load()) {   // rows committed by svs_index_staging_commit may still be in flight
-    std::lock_guard<std::mutex> lk(idx->stg_mu);
-    if (idx->stg.st) HIP_TRY(hipStreamSynchronize(idx->stg.st));
-    idx->staging_pending.store(false);
-  }
+  if ((rc = staging_wait(idx)) != SVS_OK) return rc;
   const bool path_a = k > 0 && n > SORT_CAP && count <= SEL_KMAX;
   // Fused top-k epilogue (no score matrix) for the batched kernels; a query whose
   // candidate list overflows comes back marked and is re-run by the caller.  The prefix
@@ -1612,6 +1622,7 @@ static void coalesced_pass(svs_index* idx, std::vector<svs_index::Waiter*>& batc
   const std::string err = rc == SVS_OK ? std::string() : std::string(svs_last_error());
   idx->co_passes.fetch_add(1);
   idx->co_queries.fetch_add(nb);
+  idx->co_sizes[std::min(nb, 256)].fetch_add(1);
   std::lock_guard<std::mutex> lk(idx->co_mu);
   for (int i = 0; i < nb; ++i) {
     svs_index::Waiter* w = batch[i];
@@ -1641,6 +1652,7 @@ int32_t svs_index_search(svs_index* idx, const float* queries, int32_t nq, int32
   {
     std::unique_lock<std::mutex> lk(idx->co_mu);
     idx->co_pending.push_back(&me);
+    if (idx->co_hold > 0) idx->co_hold_cv.notify_all();
     if (!idx->co_busy) { idx->co_busy = true; me.lead = true; }
     else me.cv.wait(lk, [&] { return me.done || me.lead; });
   }
@@ -1649,7 +1661,12 @@ int32_t svs_index_search(svs_index* idx, const float* queries, int32_t nq, int32
     std::vector<svs_index::Waiter*> batch;
     while (!me.done) {
       {
-        std::lock_guard<std::mutex> lk(idx->co_mu);
+        std::unique_lock<std::mutex> lk(idx->co_mu);
+        if (idx->co_hold > 0) {   // (tests / benchmarks: a pass of a chosen size; bounded, so a miscounted test cannot hang)
+          const int want = idx->co_hold;
+          idx->co_hold_cv.wait_for(lk, std::chrono::seconds(5), [&] { return (int)idx->co_pending.size() >= want; });
+          idx->co_hold = 0;
+        }
         // whole kernel tiles: the batched kernels cost the same for 33 queries as for 64 (f32: 1.8 vs 1.2 ms for
         // 32), so a queue that does not fill the next tile size leaves its tail for the following pass
         size_t take = std::min<size_t>(idx->co_pending.size(), 256);
@@ -1688,6 +1705,21 @@ int32_t svs_index_coalesce_stats(svs_index* idx, int64_t* passes, int64_t* queri
   return SVS_OK;
 }
 
+int32_t svs_index_coalesce_hold(svs_index* idx, int32_t n) {
+  if (!idx) return fail(SVS_ERR_INVALID, "null index");
+  if (n < 0 || n > 256) return fail(SVS_ERR_INVALID, "svs_index_coalesce_hold: 0 <= n <= 256");
+  std::lock_guard<std::mutex> lk(idx->co_mu);
+  idx->co_hold = n;
+  return SVS_OK;
+}
+
+int32_t svs_index_coalesce_sizes(svs_index* idx, int64_t* out, int32_t cap) {
+  if (!idx) return fail(SVS_ERR_INVALID, "null index");
+  if (!out || cap < 0 || cap > 257) return fail(SVS_ERR_INVALID, "svs_index_coalesce_sizes: out must hold cap <= 257 counters");
+  for (int s = 0; s < cap; ++s) out[s] = idx->co_sizes[s].load();
+  return SVS_OK;
+}
+
 int32_t svs_index_search_device(svs_index* idx, const float* dev_queries, int32_t nq, int32_t d,
                                 int32_t k, float* dev_out_scores, int64_t* dev_out_rows,
                                 int32_t* out_count, void* hip_stream) {
@@ -1722,6 +1754,7 @@ int32_t svs_index_scores(svs_index* idx, const float* query, int32_t d, float* o
   if (rc != SVS_OK) return rc;
   if (!out_scores) return fail(SVS_ERR_INVALID, "null output");
   HIP_TRY(hipSetDevice(idx->device));
+  if ((rc = staging_wait(idx)) != SVS_OK) return rc;
   Ctx* c = nullptr;
   if ((rc = ctx_acquire(idx, nullptr, true, &c)) != SVS_OK) return rc;
   struct CtxGuard { svs_index* i; Ctx* c; ~CtxGuard() { ctx_release(i, c); } } cg{idx, c};
@@ -1751,6 +1784,7 @@ int32_t svs_index_top_pairs(svs_index* idx, int32_t k, float* out_scores, int64_
   HIP_TRY(hipSetDevice(idx->device));
   Ctx* c = nullptr;
   int rc;
+  if ((rc = staging_wait(idx)) != SVS_OK) return rc;
   if ((rc = ctx_acquire(idx, nullptr, true, &c)) != SVS_OK) return rc;
   struct CtxGuard { svs_index* i; Ctx* c; ~CtxGuard() { ctx_release(i, c); } } cg{idx, c};
   // Small corpora: materialise n x n like the reference (src/svs/kb.py:1651).  Past n^2 = 2^32 scores
@@ -1766,6 +1800,7 @@ int32_t svs_index_debug_dequant(svs_index* idx, int64_t row0, int64_t nrows, flo
   if (row0 < 0 || nrows < 0 || row0 + nrows > idx->n) return fail(SVS_ERR_INVALID, "row range out of bounds");
   if (nrows == 0 || idx->d == 0) return SVS_OK;
   HIP_TRY(hipSetDevice(idx->device));
+  { int rc = staging_wait(idx); if (rc != SVS_OK) return rc; }
   const size_t cnt = (size_t)nrows * idx->d;
   if (idx->dtype == SVS_DTYPE_F32) {
     HIP_TRY(hipMemcpy2D(out, (size_t)idx->d * sizeof(float), (const float*)idx->rows + row0 * idx->ld,

@@ -306,5 +306,15 @@ class DeviceIndex:
         _native.check(self._lib.svs_index_coalesce_stats(self._handle(), C.byref(p), C.byref(q)))
         return p.value, q.value
 
+    def coalesce_hold(self, n: int) -> None:
+        """The next coalesced pass waits (at most 5 s) for n queued callers (svs_index_coalesce_hold; tests)."""
+        _native.check(self._lib.svs_index_coalesce_hold(self._handle(), int(n)))
+
+    def coalesce_sizes(self) -> dict:
+        """{queries per pass: passes} of the coalescing path (svs_index_coalesce_sizes)."""
+        out = (C.c_int64 * 257)()
+        _native.check(self._lib.svs_index_coalesce_sizes(self._handle(), out, 257))
+        return {s: int(out[s]) for s in range(257) if out[s]}
+
     def set_variant(self, variant: int) -> None:
         _native.check(self._lib.svs_index_set_variant(self._handle(), int(variant)))

@@ -47,8 +47,8 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
     tr = terminalreporter
     tr.write_sep("-", "parity: ranks that differ from the reference's golden row order")
     for name, rec in PARITY_SWAPS.items():
-        tr.write_line(f"{name}: single-query path {rec['single']}, batch path {rec['batch']} "
-                      f"(min adjacent f64 gap {rec['min_gap']})")
+        tr.write_line(f"{name}: single-query path {rec['single']}, batch path {rec['batch']}, "
+                      f"coalesced route {rec.get('coalesced')} (min adjacent f64 gap {rec['min_gap']})")
     out_dir = os.path.join(ROOT, "gpurun_out")
     try:
         os.makedirs(out_dir, exist_ok=True)

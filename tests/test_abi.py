@@ -133,3 +133,22 @@ def test_c_callers_coalesce(gpu, tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.startswith("ok"), (out.returncode, out.stdout, out.stderr)
     print(out.stdout.strip())
+
+
+def test_c_multi_mask_race_program_builds(tmp_path):
+    """CPU: tests/c/multi_mask_race.c compiles and links against the ABI."""
+    import shutil
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    assert os.path.exists(_build_c(tmp_path, "multi_mask_race"))
+
+
+@pytest.mark.gpu
+def test_c_caller_masks_rows_while_multi_searches_run(gpu, tmp_path):
+    """svs_index_mask_rows through svs_multi_shard while svs_multi_search(k = n) runs on three other threads:
+    every search answers with the rows there are (tests/c/multi_mask_race.c)."""
+    import subprocess
+    exe = _build_c(tmp_path, "multi_mask_race")
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.startswith("ok"), (out.returncode, out.stdout, out.stderr)
+    print(out.stdout.strip())

@@ -180,4 +180,23 @@ def test_streaming_cold_start_equals_matrix_upload(gpu, tmp_path, dtype, d):
     assert idx2.search(vecs[3], 1)[0][1] == 3
     idx2.staging_finish()
     assert idx2.shape == (50, d)
-    idx2.release(); ref.release(); kb.close()
+    idx2.release()
+    # ... and so does every other reader of the rows (scores, pairwise, the debug read-back): a full block this
+    # time (32 MiB in flight behind the commit), each reader on a fresh index, before svs_index_staging_finish
+    full = (32 << 20) // (d * 4)
+    big = np.tile(vecs, (full // n + 1, 1))[:full]
+    want = DeviceIndex(big[:full], dtype=dtype)
+    for reader in ("scores", "stored_rows", "top_pairs"):
+        idx3 = DeviceIndex.empty(d, dtype=dtype, reserve=full)
+        blk = idx3.staging_acquire()
+        blk[:full] = big
+        idx3.staging_commit(full)
+        if reader == "scores":
+            assert np.array_equal(idx3.scores(vecs[11]), want.scores(vecs[11]))
+        elif reader == "stored_rows":
+            assert np.array_equal(idx3.stored_rows(full - 64, 64), want.stored_rows(full - 64, 64))
+        else:
+            assert idx3.top_pairs(5) == want.top_pairs(5)
+        idx3.staging_finish()
+        idx3.release()
+    want.release(); ref.release(); kb.close()

@@ -61,8 +61,9 @@ def test_search_golden(gpu, case):
     position, swaps == 0, whatever the recorded gap.  (make_golden's check: on all of these the
     reference's order equals the order of the correctly rounded f64 scores, so nothing about them
     is a coin flip of numpy's.)  The `uniform` cases (the reference notebook's recipe: all scores
-    inside [0.71, 0.78], adjacent gaps of ~3e-7 against numpy's own ~2e-7 error) and the batch
-    path (MFMA summation order) keep the explained-swap tolerance of compare.py."""
+    inside [0.71, 0.78], adjacent gaps of ~3e-7 against numpy's own ~2e-7 error) keep the
+    explained-swap tolerance of compare.py.  Since round 3 the batch entry and the coalesced route
+    (MFMA summation order) are gated the same way: 0 differing positions on the gaussian cases."""
     import conftest
     m, qs = corpus_and_query(case["kind"], case["seed"], case["n"], case["d"], case["nq"])
     idx = _index(m)
@@ -82,12 +83,40 @@ def test_search_golden(gpu, case):
     for qi, q in enumerate(qs):
         batch += assert_topk_parity(bs[qi], br[qi], case["scores"][qi], case["rows"][qi], truths[qi],
                                     label=f'{case["note"]} batch q{qi}')
+    # the route callers get under load (svs_index_set_coalesce, on by default behind KB.retrieve: the executor
+    # threads of reference src/svs/kb.py:1184-1190): passes of chosen sizes, formed out of concurrent single-query
+    # calls, answered by the 16-query streaming kernel (2 .. 16), the tiled MFMA kernels (17 ..) and, from
+    # 131,072 rows and 16 queries up, their fused top-k epilogues.  Every caller's answer against the fixture.
+    coalesced = 0
+    idx.set_coalesce(True)
+    before = idx.coalesce_sizes()
+    sizes = (2, 7, 16, 32, 64) if case["n"] > 1 else (2,)
+    for size in sizes:
+        got = [None] * size
+        idx.coalesce_hold(size)
+
+        def caller(t):
+            got[t] = idx.search(qs[t % len(qs)], case["k"])
+
+        ts = [threading.Thread(target=caller, args=(t,)) for t in range(size)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        for t in range(size):
+            qi = t % len(qs)
+            coalesced += assert_topk_parity([s for s, _ in got[t]], [i for _, i in got[t]], case["scores"][qi], case["rows"][qi],
+                                            truths[qi], label=f'{case["note"]} coalesced pass of {size}, caller {t}')
+    after = idx.coalesce_sizes()
+    made = {s: after.get(s, 0) - before.get(s, 0) for s in after}
+    for size in sizes:
+        assert made.get(size, 0) >= 1, f"no pass of {size} queries was formed: {made}"
+    idx.set_coalesce(False)
     idx.release()
     gaps = [g for g in case["min_adjacent_gap_f64"] if g is not None]
     conftest.PARITY_SWAPS[f'{case["kind"]} {case["n"]}x{case["d"]} k={case["k"]} ({case["note"]})'] = {
-        "single": single, "batch": batch, "queries": case["nq"], "min_gap": min(gaps) if gaps else None}
+        "single": single, "batch": batch, "coalesced": coalesced, "queries": case["nq"], "min_gap": min(gaps) if gaps else None}
     if case["kind"] == "gaussian":
-        assert single == 0
+        # bit-exact row order on every route: alone, as a batch, and coalesced with other callers
+        assert single == 0 and batch == 0 and coalesced == 0, (single, batch, coalesced)
 
 
 def test_nan_scores_rank_largest(gpu):

@@ -101,7 +101,14 @@ int run(int64_t n, int d, int nq, int rounds) {
   CK(hipMemcpy(a.Q, h.data() + 12346, (size_t)nq_pad * a.ldb, hipMemcpyHostToDevice));   // (an EVEN offset: the exponent mask sits on the odd bytes; an odd one fills the queries with inf / NaN)
   CK(hipMalloc(&a.st, (size_t)nq * SCR_WORDS * 4)); CK(hipMemset(a.st, 0, (size_t)nq * SCR_WORDS * 4));
   CK(hipMalloc(&a.cand, (size_t)nq * CAND_CAP * 8)); CK(hipMalloc(&a.thr, nq * 4)); CK(hipMalloc(&a.rs, n * 4)); CK(hipMemset(a.rs, 0, n * 4));
-  { std::vector<float> t(nq, real ? 2.49f / sqrtf((float)d) : 1e30f); CK(hipMemcpy(a.thr, t.data(), nq * 4, hipMemcpyHostToDevice)); }
+  {
+    // the threshold the prefix pass would hand the epilogue: the k-th best (k = 100) of max(16384, n / 64) rows,
+    // in sigmas of the score distribution (2.49 at a 16,384-row prefix, 3.22 at configs[4]'s 156,250)
+    const double prefix = std::max(16384.0, (double)n / 64.0), p = 100.0 / prefix;
+    const double t = sqrt(-2.0 * log(p)), z = t - (2.515517 + 0.802853 * t + 0.010328 * t * t) / (1.0 + 1.432788 * t + 0.189269 * t * t + 0.001308 * t * t * t);
+    printf("thresholds: %.2f sigma (prefix %.0f rows)\n", z, prefix);
+    std::vector<float> th(nq, real ? (float)z / sqrtf((float)d) : 1e30f); CK(hipMemcpy(a.thr, th.data(), nq * 4, hipMemcpyHostToDevice));
+  }
   if (real && EB == 1) {   // row / query scales: raw e4m3 dot products come out ~ N(0, d * 124^4)
     std::vector<float> sc((size_t)n, 1.0f / (124.f * sqrtf((float)d)));
     CK(hipMemcpy(a.rs, sc.data(), (size_t)n * 4, hipMemcpyHostToDevice));
@@ -121,7 +128,9 @@ int run(int64_t n, int d, int nq, int rounds) {
 #else             // round 3's working set
   const V vs[] = {{"round-1 tiled 256x256", launch_tiled<EB>}, {"phased", launch_phased<EB, 0>}, {"phased, corpus pieces nontemporal", launch_phased<EB, 20>},
                   {"phased, two-sweep epilogue on every tile", launch_phased<EB, 32>}, {"phased, no epilogue", launch_phased<EB, 14>},
-                  {"phased, LDS-DMA + barriers only", launch_phased<EB, 5>}};
+                  {"phased, LDS-DMA + barriers only", launch_phased<EB, 5>},
+                  {"phased, nt, corpus addressed tile-major (timing only)", launch_phased<EB, 40>},
+                  {"phased, tile-major, LDS-DMA + barriers only", launch_phased<EB, 45>}};
 #endif
   const int NVALL = sizeof(vs) / sizeof(vs[0]);
   const char* only = getenv("PGB_ONLY");          // e.g. PGB_ONLY=2 runs variant 2 alone (fault hunting)

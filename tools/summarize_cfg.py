@@ -29,7 +29,17 @@ def newest(pat):
 
 
 short = lambda k: k.split("(")[0]
-out = {"tag": tag, "config": name, "command": cmd, "kernels": {}, "pmc": {}}
+def git_head():
+    """The commit the profiled tree was at (the GPU box has no .git: summarise right after the run, before the next commit)."""
+    import subprocess
+    try:
+        h = subprocess.run(["git", "-C", root, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, check=True).stdout.strip()
+        dirty = subprocess.run(["git", "-C", root, "status", "--porcelain", "--", "svs_amd", "bench.py", "tools/prof_batch.py"], capture_output=True, text=True).stdout.strip()
+        return h + ("+uncommitted" if dirty else "")
+    except Exception:
+        return os.environ.get("SVS_GIT_HEAD", "unrecorded")
+
+out = {"tag": tag, "git_head": git_head(), "config": name, "command": cmd, "kernels": {}, "pmc": {}}
 stats = newest(os.path.join(src, f"prof_{tag}_{name}_trace", "*", "*_kernel_stats.csv"))
 if stats:
     shutil.copy(stats, os.path.join(dst, f"{tag}_{name}_kernel_stats.csv"))

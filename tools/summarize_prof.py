@@ -41,7 +41,16 @@ for k, v in pmc.items():
     v["hbm_read_bytes_per_launch"] = rd
     v["hbm_write_bytes_per_launch"] = wr
     v["hbm_bytes_per_launch"] = rd + wr
-out = {"tag": tag, "kernels": kern, "pmc": pmc,
+def git_head():
+    """The commit the profiled tree was at (the GPU box has no .git: summarise right after the run, before the next commit)."""
+    import subprocess
+    try:
+        h = subprocess.run(["git", "-C", root, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, check=True).stdout.strip()
+        dirty = subprocess.run(["git", "-C", root, "status", "--porcelain", "--", "svs_amd", "bench.py", "tools/prof_batch.py"], capture_output=True, text=True).stdout.strip()
+        return h + ("+uncommitted" if dirty else "")
+    except Exception:
+        return os.environ.get("SVS_GIT_HEAD", "unrecorded")
+out = {"tag": tag, "git_head": git_head(), "kernels": kern, "pmc": pmc,
        "note": "FETCH_SIZE x2 (gfx950 reports half of a wide coalesced read), KiB units; WRITE_SIZE exact"}
 json.dump(out, open(os.path.join(dst, f"{tag}_summary.json"), "w"), indent=1)
 bench = os.path.join(src, f"prof_{tag}_trace.json")
