@@ -72,11 +72,16 @@ constexpr int PG_THREADS = 512;
 #ifndef PG_DMA_AT1
 #define PG_DMA_AT1 1
 #endif
+// The counted wait of a phase: everything but the youngest 5 half-tiles (4 when the pieces are issued between the
+// MFMAs) must have landed.  An A half-tile is 2 pieces per wave, a B half-tile PB (2 at 256-query tiles, 1 at
+// 128-query tiles); the half-tiles alternate B A B A, so the count depends on what the YOUNGEST one is:
+//   youngest = A: A B A B A = 6 + 2 PB  (4 youngest: 4 + 2 PB),   youngest = B: B A B A B = 4 + 3 PB  (4 + 2 PB)
 #ifdef PG_VMCNT_FORCE   // (tools: DMA-only ablations with more pieces in flight than the ring allows -- results are wrong)
-#define PG_VMCNT PG_VMCNT_FORCE
+#define PG_VMCNT_OF(kind) PG_VMCNT_FORCE
 #else
-#define PG_VMCNT (kDmaInMma ? 8 : 10)
+#define PG_VMCNT_OF(kind) (kDmaInMma ? 4 + 2 * PB : (((kind) & 1) ? 6 + 2 * PB : 4 + 3 * PB))
 #endif
+#define PG_VMCNT PG_VMCNT_OF(0)   // the smaller of the two: what a wait that must hold in every phase uses
 
 #ifdef PG_CLOCKS   // tools/gemm_phased_bench.hip only: shader cycles and 100 MHz ticks a workgroup spent in the kernel
 __device__ unsigned long long* pg_clock_buf;
@@ -206,11 +211,11 @@ __device__ __forceinline__ void pg_read_a(u32x4 (&fa)[4][2], const unsigned (&ad
     PG_DS_READ(fa[mt][1], b1, (SLOT & 3) * 16384 + mt * 2048);
   }
 }
-template <int SLOT>
-__device__ __forceinline__ void pg_read_b(u32x4 (&fb)[2][2], const unsigned (&adr)[2]) {
+template <int SLOT, int NTQ>
+__device__ __forceinline__ void pg_read_b(u32x4 (&fb)[NTQ][2], const unsigned (&adr)[2]) {
   const unsigned b0 = pg_slot_base<SLOT>(adr[0]), b1 = pg_slot_base<SLOT>(adr[1]);
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
+  for (int nt = 0; nt < NTQ; ++nt) {
     PG_DS_READ(fb[nt][0], b0, (SLOT & 3) * 16384 + nt * 2048);
     PG_DS_READ(fb[nt][1], b1, (SLOT & 3) * 16384 + nt * 2048);
   }
@@ -225,6 +230,9 @@ __device__ __forceinline__ void pg_landed_a(u32x4 (&fa)[4][2]) {
 }
 __device__ __forceinline__ void pg_landed_b(u32x4 (&fb)[2][2]) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[1][0]), "+v"(fb[1][1])::"memory");
+}
+__device__ __forceinline__ void pg_landed_b(u32x4 (&fb)[1][2]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[0][0]), "+v"(fb[0][1])::"memory");
 }
 
 // ---- side region of the LDS, behind the 128 KiB ring (fused top-k and fp8 scales) ------------
@@ -289,16 +297,23 @@ __device__ __forceinline__ void pg_lds_write_u32(unsigned adr, uint32_t x) { asm
 // EXP != 0: timing-only ablations for tools/gemm_phased_bench.hip (results are wrong): 1 no LDS-DMA
 // in the main loop, 2 no fragment reads, 3 no MFMAs, 7 no stagger (all waves in the same phase),
 // 14 no epilogue.
-template <bool FUSE, int EB, int EXP = 0>
+// QT: queries per output tile.  256: four wave columns of 64 queries (two 16-query MFMA columns per quadrant).
+// 128 (panels of 65 .. 128 queries -- what a coalescer forms on a reduced-precision index): four wave columns of
+// 32 queries, ONE 16-query MFMA column per quadrant; a B half-tile is then 64 queries = one LDS-DMA piece per
+// wave (8 KiB of its 16 KiB slot), and the counted waits below follow from the pieces per half-tile.
+template <bool FUSE, int EB, int EXP = 0, int QT = 256>
 __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
     const uint8_t* __restrict__ M, const uint8_t* __restrict__ Q, float* __restrict__ scores,
     int64_t n, int ldb, int64_t sstride, int nq, int gx, int gy, uint32_t* __restrict__ fstate_words, int fstate_stride,
     uint64_t* __restrict__ fcand, uint32_t fcap, const float* __restrict__ fthr, int fthr_stride,
     const float* __restrict__ rscale, const float* __restrict__ qscale, const TgPairs pairs = TgPairs{}) {
   static_assert(EB == 1 || EB == 2, "f16 or fp8 operands");
+  static_assert(QT == 256 || QT == 128, "256- or 128-query tiles");
   extern __shared__ u32x4 pg_lds[];
   PG_CLOCK_STAMP(0);
-  constexpr int MT = 8, NT = 4;
+  constexpr int NTQ = QT / 128;           // 16-query MFMA columns per quadrant
+  constexpr int MT = 8, NT = 2 * NTQ;
+  constexpr int PB = QT / 128;            // LDS-DMA pieces per wave in a B half-tile (an A half-tile: 2)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wave >> 2, wc = wave & 3;
@@ -330,7 +345,7 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     adrA[h] = (unsigned)(((wr * 64 + r16) * 8 + ((4 * h + g) ^ tg_swz(r16))) * 16);
-    adrB[h] = (unsigned)(((wc * 32 + r16) * 8 + ((4 * h + g) ^ tg_swz(r16))) * 16);
+    adrB[h] = (unsigned)(((wc * (16 * NTQ) + r16) * 8 + ((4 * h + g) ^ tg_swz(r16))) * 16);
   }
 
   auto tile_desc = [&](int j) __attribute__((always_inline)) {
@@ -344,10 +359,10 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
       bx = __builtin_amdgcn_readfirstlane(bx);
       by = __builtin_amdgcn_readfirstlane(by);
       t.row0 = (int64_t)bx * PG_TILE;
-      t.q0 = by * PG_TILE;
+      t.q0 = by * QT;
       const int64_t live = n - t.row0 < PG_TILE ? n - t.row0 : PG_TILE;
       t.a = pg_rsrc(M + t.row0 * ldb, (int)(live * ldb));
-      t.b = pg_rsrc(Q + (int64_t)t.q0 * ldb, PG_TILE * ldb);
+      t.b = pg_rsrc(Q + (int64_t)t.q0 * ldb, QT * ldb);
     } else {   // no such tile: zero records, every load through it is dropped
       t.row0 = 0;
       t.q0 = 0;
@@ -366,7 +381,9 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
     constexpr bool tm = (EXP == 40 || EXP == 45) && (kind & 1);   // (timing-only: the corpus addressed as if tile-major -- a k-tile of a row tile one contiguous 32 KiB block)
     const int soff = (EXP == 21 || EXP == 25) ? 0 : (tm ? kt * (PG_TILE * TG_BKB) : kt * TG_BKB);   // (ablation 21: always the first k-tile: L2 hits)
     const __amdgpu_buffer_rsrc_t rs = (kind & 1) ? (next ? nxt.a : cur.a) : (next ? nxt.b : cur.b);
-    const int rows = (kind & 1) ? jj * 128 + (kind >> 1) * 64 : wr * 32 + jj * 128 + (kind >> 1) * 32;
+    // B, QT = 128: half-tile row li = li0 (0 .. 63) holds query (li >> 4) * 32 + h * 16 + (li & 15) = li0 + (wave >> 1) * 16 + h * 16
+    const int rows = (kind & 1) ? jj * 128 + (kind >> 1) * 64
+                                : (QT == 256 ? wr * 32 + jj * 128 + (kind >> 1) * 32 : (wave >> 1) * 16 + (kind >> 1) * 16);
     const int vo = tm ? pg_voff(vbase_tm, rows * TG_BKB) : pg_voff(vbase, rows * ldb);
     const unsigned dst = pg_lds_dest<slot * PG_SLOT * 16 + jj * 8192>(wave_lds);
     if constexpr ((EXP == 20 || EXP == 40 || EXP == 45) && (kind & 1))   // (corpus rows nontemporal: the single-query-tile form, see launch_tiled_eb)
@@ -376,7 +393,7 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
   };
   auto stage = [&](auto KIND, auto SLOT, auto NEXT, int kt) __attribute__((always_inline)) {
     stage_piece(KIND, SLOT, NEXT, kt, std::integral_constant<int, 0>{});
-    stage_piece(KIND, SLOT, NEXT, kt, std::integral_constant<int, 1>{});
+    if constexpr ((decltype(KIND)::value & 1) || PB == 2) stage_piece(KIND, SLOT, NEXT, kt, std::integral_constant<int, 1>{});
   };
   // side data of tile `t` into copy `par`: every wave issues the same instructions (waves 4-7
   // repeat waves 0-3: same bytes to the same place), 256 bytes each
@@ -389,7 +406,7 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
     const int col = tid_s & 255;   // = (wave & 3) * 64 + lane
     char* side = (char*)pg_lds;
     if constexpr (FUSE) {
-      const int live = nq - t.q0 < PG_TILE ? nq - t.q0 : PG_TILE;
+      const int live = nq - t.q0 < QT ? nq - t.q0 : QT;
       // (stride 0: one threshold for every query -- pair mode -- is one 4-byte record read by every lane)
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(fthr + (int64_t)t.q0 * fthr_stride), 0,
                                                                           fthr_stride ? live * fthr_stride * 4 : 4, 0x00020000);
@@ -399,24 +416,24 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
     if constexpr (EB == 1) {
       const int64_t lrows = n - t.row0 < PG_TILE ? n - t.row0 : PG_TILE;
       const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(rscale + t.row0), 0, (int)lrows * 4, 0x00020000);
-      const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)(qscale + t.q0), 0, PG_TILE * 4, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)(qscale + t.q0), 0, QT * 4, 0x00020000);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rr, (__attribute__((address_space(3))) void*)(side + PG_SIDE_RS + par * 1024 + (wave & 3) * 256), 4, col * 4, 0, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (__attribute__((address_space(3))) void*)(side + PG_SIDE_QS + par * 1024 + (wave & 3) * 256), 4, col * 4, 0, 0, 0);
     }
   };
 
   f32x4_t acc[MT][NT];
-  u32x4 fa[4][2], fb0[2][2], fb1[2][2];
+  u32x4 fa[4][2], fb0[NTQ][2], fb1[NTQ][2];
   if constexpr (EXP == 2 || EXP == 5 || EXP == 25 || EXP == 26 || EXP == 45) {   // (ablation without fragment reads: defined operands)
     const u32x4 c = {0x3c003c00u + (uint32_t)lane, 0x3c003c00u, 0x38003800u, 0x3c003c00u};
 #pragma unroll
     for (int i = 0; i < 4; ++i) fa[i][0] = fa[i][1] = c;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) fb0[i][0] = fb0[i][1] = fb1[i][0] = fb1[i][1] = c;
+    for (int i = 0; i < NTQ; ++i) fb0[i][0] = fb0[i][1] = fb1[i][0] = fb1[i][1] = c;
   }
   // one quadrant: rows 64 i .. 64 i + 63, queries 32 j .. 32 j + 31 of the wave tile
   // s0 / s1: the phase's two LDS-DMA pieces when they are issued BETWEEN the MFMAs (kDmaInMma)
-  auto mma = [&](auto I, auto J, const u32x4 (&fb)[2][2], auto&& s0, auto&& s1) __attribute__((always_inline)) {
+  auto mma = [&](auto I, auto J, const u32x4 (&fb)[NTQ][2], auto&& s0, auto&& s1) __attribute__((always_inline)) {
     constexpr int i = decltype(I)::value, j = decltype(J)::value;
     if constexpr (EB == 2) {
 #pragma unroll
@@ -424,9 +441,9 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
-            acc[i * 4 + mt][j * 2 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
-                __builtin_bit_cast(h8, fa[mt][h]), __builtin_bit_cast(h8, fb[nt][h]), acc[i * 4 + mt][j * 2 + nt], 0, 0, 0);
+          for (int nt = 0; nt < NTQ; ++nt)
+            acc[i * 4 + mt][j * NTQ + nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                __builtin_bit_cast(h8, fa[mt][h]), __builtin_bit_cast(h8, fb[nt][h]), acc[i * 4 + mt][j * NTQ + nt], 0, 0, 0);
 #if PG_DMA_STAGGER
           // the four waves of a group share the CU's vector-memory front end (64 B/clk: 16 cycles per
           // piece): wave wc issues after MFMA pair wc, so no piece queues behind another wave's
@@ -446,11 +463,11 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
         const u32x4 al = fa[mt][0], ah = fa[mt][1];
         const i32x8 x = {(int)al.x, (int)al.y, (int)al.z, (int)al.w, (int)ah.x, (int)ah.y, (int)ah.z, (int)ah.w};
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+        for (int nt = 0; nt < NTQ; ++nt) {
           const u32x4 bl = fb[nt][0], bh = fb[nt][1];
           const i32x8 y = {(int)bl.x, (int)bl.y, (int)bl.z, (int)bl.w, (int)bh.x, (int)bh.y, (int)bh.z, (int)bh.w};
-          acc[i * 4 + mt][j * 2 + nt] =
-              __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(x, y, acc[i * 4 + mt][j * 2 + nt], 0, 0, 0, 0, 0, 0);
+          acc[i * 4 + mt][j * NTQ + nt] =
+              __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(x, y, acc[i * 4 + mt][j * NTQ + nt], 0, 0, 0, 0, 0, 0);
         }
         if (mt == 0) { __builtin_amdgcn_sched_barrier(0); s0(); __builtin_amdgcn_sched_barrier(0); }
         if (mt == 2) { __builtin_amdgcn_sched_barrier(0); s1(); __builtin_amdgcn_sched_barrier(0); }
@@ -466,7 +483,7 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
   do {                                                                      \
     if constexpr (kStage && !kDmaInMma) stage(PG_C(KIND), PG_C(SLOT), PG_C(NEXT), KT_); \
     if (LGKM8 && kRead && !kDmaInMma) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");  \
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PG_VMCNT) : "memory");         \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PG_VMCNT_OF(KIND)) : "memory");   \
     PG_STAMP(PH, 0);                                                        \
     __builtin_amdgcn_s_barrier();                                           \
     if constexpr (kRead) { LAND; }                                          \
@@ -535,6 +552,9 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
       const uint32_t nw = pg_lds_read_u32(PG_SIDE_CNT + (f_pp * 8 + w) * 4);
       if ((uint32_t)i < nw) {
         const uint32_t code = pg_lds_read_u32(PG_SIDE_KEY + (f_pp * PG_PARK + e) * 8 + 4);
+        // (a padded query of the last query tile can park a candidate only through a NaN score -- its threshold is
+        //  +inf -- and has no list: dropped here and in flush_b)
+        if (f_q0 + (int)(code >> 8) >= nq) continue;
         uint32_t* p = fstate_words + (int64_t)(f_q0 + (int)(code >> 8)) * fstate_stride;
         const uint32_t one = 1u;
         asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(fslot[r]) : "v"(p), "v"(one) : "memory");
@@ -555,6 +575,7 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
       if ((uint32_t)i < nw && fslot[r] < fcap) {
         const uint64_t sc = pg_lds_read_u64(PG_SIDE_KEY + (f_pp * PG_PARK + e) * 8);   // (score bits, code)
         const uint32_t code = (uint32_t)(sc >> 32);
+        if (f_q0 + (int)(code >> 8) >= nq) continue;
         fcand[(int64_t)(f_q0 + (int)(code >> 8)) * fcap + fslot[r]] =
             ((uint64_t)score_key(__builtin_bit_cast(float, (uint32_t)sc)) << 32) | (uint32_t)(pairs.row_base + f_row0 + (code & 255u));
       }
@@ -563,7 +584,7 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
 
   // ---- epilogue of one tile: scales (fp8), then scores out (materialised) or candidates parked
   auto epilogue = [&](const PgTile& t, int par) __attribute__((always_inline)) {
-    const int wrow = wr * 128, wq = wc * 64;
+    const int wrow = wr * 128, wq = wc * (QT / 4);
     int lane_e = (int)threadIdx.x;   // (the copy is made opaque BEFORE the mask: `threadIdx.x & 63` itself was kept live -- and spilled in the fp8 form)
     asm volatile("" : "+v"(lane_e));
     lane_e &= 63;
@@ -695,6 +716,9 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
         for (int j = 0; j < NT; ++j) {
           const int ql = wq + j * 16 + r16;
           thr[j] = pg_lds_read_f32(PG_SIDE_THR + par * 1024 + ql * 4);
+          // (the last query tile of a batch that is not a whole number of tiles: its padded queries -- zero vectors
+          //  -- take no part: nothing reaches +inf but a NaN, and the flush drops those)
+          if (t.q0 + ql >= nq) thr[j] = __builtin_inff();
           base[j] = (uint32_t)(lr0 | (ql << 8));
         }
         auto val = [&](int i, int j, int r) { return acc[i][j][r]; };
@@ -738,18 +762,27 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
       // pair mode: tiles wholly above the diagonal are ordinary tiles, tiles wholly on or below it hold nothing,
       // the few that straddle it (or hold queries of the previous chunk) take the masked path
       const long long prow0 = pairs.row_base + t.row0, pq0 = pairs.query_row0 + t.q0;
-      const bool pair_plain = !pairs.on || (prow0 > pq0 + PG_TILE - 1 && pq0 >= pairs.first_query);
+      const bool pair_plain = !pairs.on || (prow0 > pq0 + QT - 1 && pq0 >= pairs.first_query);
       const bool pair_empty = pairs.on && prow0 + PG_TILE - 1 <= pq0;
       // Interior tiles take the two branch-free sweeps when the wave's last tile held many survivors (configs[2]:
       // ~50 per wave and tile, a third of the registers hold one) and the grouped compare-and-branch path when it
       // held few (configs[4], thresholds from a 156 k-row prefix: ~5 per wave and tile -- the sweeps' 7 vector
       // instructions per register against 1 + a scalar test per four).  Either is exact whatever survives.
-      if (pair_empty) wcount = 0;
-      else if (lim == PG_TILE && t.q0 + PG_TILE <= nq && pair_plain && EXP != 31) {
+      // (one call site per form of pass(): each is ~10 k lines of ISA)
+      bool general = !pair_empty && !(lim == PG_TILE && pair_plain && EXP != 31);   // (EXP 31: the branchy path everywhere, A/B)
+      bool grouped_full = false;
+      if (!pair_empty && !general) {
+        // (a partly filled last QUERY tile is an interior tile too: the sweeps give its padded queries +inf
+        //  thresholds; only the grouped path needs the per-lane query mask, i.e. the general form of pass())
         bool grouped = last_wcount <= PG_SPARSE_MAX;
         if (!grouped) grouped = sweep();
-        if (grouped) pass(std::true_type{}, std::true_type{});
-      } else pass(std::false_type{}, std::false_type{});   // (EXP 31: the branchy path everywhere, A/B)
+        if (grouped) {
+          if (t.q0 + QT <= nq) grouped_full = true;
+          else general = true;
+        }
+      }
+      if (grouped_full) pass(std::true_type{}, std::true_type{});
+      if (general) pass(std::false_type{}, std::false_type{});
       last_wcount = EXP == 32 ? PG_SPARSE_MAX + 1 : wcount;   // (EXP 32: the sweeps on every interior tile, A/B)
       if (lane == 0) pg_lds_write_u32(PG_SIDE_CNT + (par * 8 + wave) * 4, (uint32_t)(wcount < WCAP ? wcount : WCAP));
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // parked entries written before this wave's next barrier
@@ -792,8 +825,8 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
       // (flush_b); the returned slots live in registers only across this straight-line stretch.
       // INVARIANT (what the counted wait in flush_b rests on).  flush_a's returning atomics are issued by inline asm,
       // so hipcc inserts no wait for them; they sit in the wave's in-order vmcnt queue like any load.  Between
-      // flush_a and flush_b the wave issues the LDS-DMA pieces of two k-tiles: 2 k-tiles x 4 phases x 2 pieces =
-      // PG_FLUSH_YOUNGER = 16 vector-memory instructions, all YOUNGER than the atomics.  `s_waitcnt vmcnt(PG_VMCNT)`
+      // flush_a and flush_b the wave issues the LDS-DMA pieces of two k-tiles: PG_FLUSH_YOUNGER = 16 vector-memory
+      // instructions at 256-query tiles (12 at 128-query tiles), all YOUNGER than the atomics.  `s_waitcnt vmcnt(PG_VMCNT)`
       // retires everything but the PG_VMCNT youngest, so it covers the atomics iff PG_FLUSH_YOUNGER >= PG_VMCNT.
       // A build that issues no DMA in the loop (ablations 1 and 26: kStage false) or forces a larger count
       // (PG_VMCNT_FORCE) does not have that cover and must wait vmcnt(0) instead: round 2's "no LDS-DMA in loop"
@@ -801,7 +834,7 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
       // candidate store went through a corrupted address -- the GPU memory fault of gpurun_out/pb8.log.
       // The flush needs loop iteration kt == PG_FLUSH_KT to exist in THIS loop (not in the two tail k-tiles):
       // PG_FLUSH_KT + 2 <= PG_MIN_KT - 2, and the host (phased_ok) refuses rows shorter than PG_MIN_KT k-tiles.
-      constexpr int PG_FLUSH_YOUNGER = 2 * 4 * 2;
+      constexpr int PG_FLUSH_YOUNGER = 2 * (2 * 2 + 2 * PB);   // two k-tiles: 2 A half-tiles of 2 pieces + 2 B half-tiles of PB each
       constexpr bool kFlushCovered = kStage && PG_FLUSH_YOUNGER >= PG_VMCNT;
 #ifndef PG_VMCNT_FORCE
       static_assert(EXP != 0 && EXP != 20 && EXP != 30 && EXP != 31 && EXP != 32 ? true : kFlushCovered,

@@ -641,20 +641,20 @@ int launch_tiled_bn(const svs_index* idx, Ctx* c, int64_t n_rows, int nq, float*
 }
 
 // 256 x 256 output tiles, persistent workgroups, four-phase k-tiles (gemm_phased.h)
-template <bool FUSE, int EB, int EXP = 0>
+template <bool FUSE, int EB, int EXP = 0, int QT = PG_TILE>
 int launch_phased(const svs_index* idx, Ctx* c, int64_t n_rows, int nq, float* scores, int64_t sstride,
                   FuseLaunch fl, hipStream_t st) {
   static std::once_flag once;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute((const void*)gemm_phased_kernel<FUSE, EB, EXP>, hipFuncAttributeMaxDynamicSharedMemorySize, PG_LDS_TOTAL);
+    (void)hipFuncSetAttribute((const void*)gemm_phased_kernel<FUSE, EB, EXP, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, PG_LDS_TOTAL);
   });
-  const int gx = (int)((n_rows + PG_TILE - 1) / PG_TILE), gy = (nq + PG_TILE - 1) / PG_TILE;
+  const int gx = (int)((n_rows + PG_TILE - 1) / PG_TILE), gy = (nq + QT - 1) / QT;
   const int64_t total = (int64_t)gx * gy;
   const unsigned grid = (unsigned)std::min<int64_t>(total, idx->cu_count);   // one persistent workgroup per CU
   const uint8_t* Q = EB == 2 ? (const uint8_t*)c->qh : (const uint8_t*)c->q8;
   // pair mode: the row operand starts at global row fl.pairs.row_base (n_rows counts from there)
   const int64_t rb = fl.pairs.on ? fl.pairs.row_base : 0;
-  hipLaunchKernelGGL((gemm_phased_kernel<FUSE, EB, EXP>), dim3(grid), dim3(PG_THREADS), PG_LDS_TOTAL, st,
+  hipLaunchKernelGGL((gemm_phased_kernel<FUSE, EB, EXP, QT>), dim3(grid), dim3(PG_THREADS), PG_LDS_TOTAL, st,
                      (const uint8_t*)idx->rows + (size_t)rb * idx->ld * EB, Q, scores, n_rows, (int)(idx->ld * EB), sstride, nq, gx, gy,
                      fl.state, (int)SCR_WORDS, fl.cand, (uint32_t)CAND_CAP, fl.thr, fl.thr_stride,
                      (const float*)(idx->row_scales ? idx->row_scales + rb : nullptr), (const float*)c->q8s, fl.pairs);
@@ -687,6 +687,13 @@ int launch_tiled_eb(const svs_index* idx, Ctx* c, int64_t n_rows, int nq, int bn
       return f ? launch_phased<true, EB>(idx, c, n_rows, nq, scores, sstride, fl, st)
                : launch_phased<false, EB>(idx, c, n_rows, nq, scores, sstride, fl, st);
     }
+  }
+  if constexpr (EB != 4) {
+    // 65 .. 128 queries (one query tile: the batches a coalescer forms on a reduced-precision index): the phased
+    // kernel at 128-query tiles, corpus pieces nontemporal -- HBM-bound, every corpus byte used once
+    if (bn == 128 && !fl.pairs.on && idx->variant.load() != 4 && phased_ok(idx, n_rows, nq))
+      return f ? launch_phased<true, EB, 20, 128>(idx, c, n_rows, nq, scores, sstride, fl, st)
+               : launch_phased<false, EB, 0, 128>(idx, c, n_rows, nq, scores, sstride, fl, st);
   }
   switch (bn) {
     case 32: return f ? launch_tiled_bn<32, true, EB>(idx, c, n_rows, nq, scores, sstride, fl, st) : launch_tiled_bn<32, false, EB>(idx, c, n_rows, nq, scores, sstride, fl, st);
@@ -1667,10 +1674,13 @@ int32_t svs_index_search(svs_index* idx, const float* queries, int32_t nq, int32
           idx->co_hold_cv.wait_for(lk, std::chrono::seconds(5), [&] { return (int)idx->co_pending.size() >= want; });
           idx->co_hold = 0;
         }
-        // whole kernel tiles: the batched kernels cost the same for 33 queries as for 64 (f32: 1.8 vs 1.2 ms for
-        // 32), so a queue that does not fill the next tile size leaves its tail for the following pass
+        // f32: whole kernel tiles -- the exact-f32 MFMA kernels cost the same for 33 queries as for 64 (1.8 vs 1.2 ms
+        // for 32), so a queue that does not fill the next tile size leaves its tail for the following pass.
+        // f16 / fp8: the passes are HBM-bound up to 128 queries and cost almost the same whatever they carry
+        // (1M x 1536 f16: 0.57 / 0.60 / 0.64 ms at 16 / 32 / 64 queries; fp8 0.32 / 0.33 / 0.40): cutting 40
+        // queued callers into 32 + 8 would cost two passes for the price of one, so everything queued goes out.
         size_t take = std::min<size_t>(idx->co_pending.size(), 256);
-        if (idx->co_round.load())
+        if (idx->co_round.load() && idx->dtype == SVS_DTYPE_F32)
           for (size_t g : {(size_t)128, (size_t)64, (size_t)32, (size_t)16})
             if (take > g && take < 2 * g) { take = g; break; }
         batch.assign(idx->co_pending.begin(), idx->co_pending.begin() + take);

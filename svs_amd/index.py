@@ -164,6 +164,7 @@ class DeviceIndex:
 
     def staging_commit(self, n_rows: int) -> None:
         _native.check(self._lib.svs_index_staging_commit(self._handle(), int(n_rows)))
+        self._refresh()      # the library publishes the new row count at commit: keep the wrapper's in step
 
     def staging_finish(self) -> None:
         _native.check(self._lib.svs_index_staging_finish(self._handle()))
@@ -225,6 +226,7 @@ class DeviceIndex:
         q = np.ascontiguousarray(query_vec, dtype=np.float32)
         if q.ndim != 1:
             raise ValueError(f"query must be 1-D, got shape {q.shape}")
+        self._refresh()      # svs_index_scores writes one f32 per row the HANDLE holds now (appends / commits since)
         out = np.empty(self.n, dtype=np.float32)
         h = self._pinned_handle()
         try:

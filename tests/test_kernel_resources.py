@@ -51,9 +51,10 @@ def test_no_fused_phased_kernel_uses_scratch(build_reports):
     table = _resources(build_reports[0])
     names = _demangle([n for n in table if "gemm_phased_kernel" in n])
     fused = {names[n]: table[n] for n in names if "gemm_phased_kernel<true" in names[n]}
-    # f16 and fp8, default / nontemporal-corpus / A-B forms: all of them ship in the library
-    assert len(fused) >= 8, sorted(fused)
-    assert any("<true, 1, 20>" in k for k in fused) and any("<true, 2, 0>" in k for k in fused)
+    # f16 and fp8; 256- and 128-query tiles; default / nontemporal-corpus / A-B forms: all of them ship in the library
+    assert len(fused) >= 10, sorted(fused)
+    for want in ("<true, 1, 20, 256>", "<true, 2, 0, 256>", "<true, 1, 20, 128>", "<true, 2, 20, 128>"):
+        assert any(want in k for k in fused), f"no gemm_phased_kernel{want} in the build"
     for k, r in fused.items():
         assert r["scratch"] == 0 and r["vgpr_spill"] == 0, f"{k}: {r} -- a spill reload drains the LDS-DMA ring"
         assert r["vgpr"] + r["agpr"] <= 256, f"{k}: {r} -- two waves per SIMD need <= 256 registers"
@@ -92,6 +93,6 @@ def test_no_ring_drain_between_tile_loop_header_and_k_loop(build_reports):
         # the k loop itself: counted waits only
         loop_end = next(i for i in range(inner, len(body)) if re.search(r"s_cbranch_\w+ \.LBB\d+_\d+", body[i]) and i > inner + 200)
         mfma = [l for l in body[inner:loop_end] if "v_mfma" in l]
-        assert len(mfma) >= 64, f"{pretty}: {len(mfma)} MFMAs in what should be the k loop"
+        assert len(mfma) >= 32, f"{pretty}: {len(mfma)} MFMAs in what should be the k loop (two k-tiles: 32 at fp8 128-query tiles .. 128 at f16 256-query tiles)"
         checked += 1
-    assert checked >= 8
+    assert checked >= 10

@@ -50,6 +50,57 @@ def test_phased_equals_round1_kernel_and_oracle(gpu, dtype, n, d, nq, k):
     idx.release()
 
 
+@pytest.mark.parametrize("dtype,n,d,nq,k", [
+    ("f16", 140000, 1536, 128, 100),   # one full 128-query tile, fused top-k, last row tile partial
+    ("f16", 140000, 1536, 65, 100),    # 63 padded queries (+inf thresholds in the sweeps)
+    ("f16", 9000, 128, 100, 50),       # 2 k-tiles per row, materialised scores
+    ("fp8", 140000, 3072, 128, 100),   # configs[4]'s row length
+    ("fp8", 135000, 1536, 97, 7),      # few survivors per tile: the grouped epilogue path with padded queries
+    ("fp8", 10000, 256, 66, 20),
+])
+def test_phased_128_query_tiles_equal_tiled_kernel_and_oracle(gpu, dtype, n, d, nq, k):
+    """Panels of 65 .. 128 queries (the batches a coalescer forms on a reduced-precision index, reference
+    src/svs/kb.py:1184-1190): gemm_phased_kernel<.., QT = 128> against the tiled kernel it replaces
+    (svs_index_set_variant(2): bit-identical scores and rows) and the numpy oracle on the stored corpus."""
+    from svs_amd import DeviceIndex
+    m, qs = corpus_and_query("gaussian", 1700 + n % 1000 + nq, n, d, nq)
+    idx = DeviceIndex(m, dtype=dtype)
+    s0, r0 = idx.search_batch(qs, k)
+    for rep in range(4):                 # race screen of the LDS-DMA ring at the new counted waits
+        s1, r1 = idx.search_batch(qs, k)
+        assert np.array_equal(r0, r1) and np.array_equal(s0, s1), f"run {rep} differs"
+    idx.set_variant(2)
+    s2, r2 = idx.search_batch(qs, k)
+    idx.set_variant(0)
+    assert np.array_equal(r0, r2) and np.array_equal(s0, s2), "128-query phased kernel != gemm_tiled kernel"
+    md = idx.stored_rows()
+    for qi in sorted({0, 1, nq // 2, 63, 64 % nq, nq - 1}):
+        qd = idx.stored_query(qs[qi])
+        exp = oracle.cpu_search(md, qd, k)
+        assert_topk_parity(s0[qi], r0[qi], [s for s, _ in exp], [i for _, i in exp],
+                           oracle.cpu_scores_f64(md, qd), label=f"phased-128 {dtype} {n}x{d} q{qi}")
+    idx.release()
+
+
+@pytest.mark.parametrize("dtype", ["f16", "fp8"])
+@pytest.mark.parametrize("nq", [17, 64])
+def test_small_panels_on_reduced_precision_match_oracle(gpu, dtype, nq):
+    """17 and 64 queries over f16 / fp8 (the tiled MFMA kernels at 32- and 64-query tiles, fused top-k):
+    oracle parity on the stored corpus, and batch == the per-query searches up to near ties."""
+    from svs_amd import DeviceIndex
+    n, d, k = 140000, 1536, 100
+    m, qs = corpus_and_query("gaussian", 2100 + nq, n, d, nq)
+    idx = DeviceIndex(m, dtype=dtype)
+    s0, r0 = idx.search_batch(qs, k)
+    md = idx.stored_rows()
+    for qi in sorted({0, nq // 2, nq - 1}):
+        qd = idx.stored_query(qs[qi])
+        exp = oracle.cpu_search(md, qd, k)
+        assert_topk_parity(s0[qi], r0[qi], [s for s, _ in exp], [i for _, i in exp],
+                           oracle.cpu_scores_f64(md, qd), label=f"{dtype} panel of {nq} q{qi}")
+    idx.release()
+
+
 def test_phased_odd_ktile_count_falls_back(gpu):
     """Rows with an odd number of 128-byte k-tiles (d = 192 halves = 3 tiles) are not the phased
     kernel's: the tiled kernel serves them, results as the oracle's."""

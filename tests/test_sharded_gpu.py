@@ -1,0 +1,62 @@
+"""GPU: the N > 1 pipelined device exchange with REAL ranks (two and three processes sharing the test
+box's one card over gloo): what tools/rehearse_sharded.sh did by hand in round 2.  Every rank holds its
+row block in HBM (row_offset = shard_bounds()[0]), single-query searches alternate between two HIP
+streams, `gather_every` records share one all-gather, rank 0 copies each gathered chunk home and merges
+(svs_amd/sharded.py: ShardedIndex.open / enqueue / collect -- the code bench.py --gpus N runs).  The
+merged answer must be IDENTICAL, rows and score bits, to one index over the whole corpus: a row's
+score does not depend on where it lives (reference analogue: np.dot over the whole matrix,
+src/svs/kb.py:1623, then get_top_k, src/svs/util.py:190-203)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from synth import corpus_and_query
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world,n,d,nq,k,gather_every,dtype", [
+    (2, 300_000, 384, 21, 100, 8, "f32"),    # 21 searches = two whole chunks of 8 + a partly filled last one
+    (3, 100_003, 256, 9, 50, 4, "f16"),      # uneven shards (ceil split), three ranks, half-precision corpus
+    (2, 40, 64, 5, 100, 8, "f32"),           # k > rows: every shard answers with fewer than k, padded records
+])
+def test_pipelined_exchange_with_real_ranks(gpu, tmp_path, world, n, d, nq, k, gather_every, dtype):
+    from svs_amd import DeviceIndex
+    port = _free_port()
+    out = str(tmp_path / "rank0.npz")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "sharded_gpu_worker.py"), str(r), str(world), str(port), out,
+                               str(n), str(d), str(nq), str(k), str(gather_every), dtype],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o)
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {r} failed:\n{logs[r][-3000:]}"
+    got = np.load(out)
+    m, qs = corpus_and_query("gaussian", 2024, n, d, nq)
+    whole = DeviceIndex(m, dtype=dtype)
+    count = min(k, n)
+    assert got["rows"].shape == (nq, count)
+    for i in range(nq):
+        exp = whole.search(qs[i], k)
+        assert [int(x) for x in got["rows"][i]] == [r for _, r in exp], f"query {i}: rows differ from one index"
+        assert [float(x) for x in got["scores"][i]] == [s for s, _ in exp], f"query {i}: score bits differ from one index"
+    whole.release()
