@@ -441,6 +441,22 @@ def main():
                 p1, a1 = idx.coalesce_stats()
                 concurrent["queries_per_corpus_pass"] = (a1 - a0) / max(p1 - p0, 1)
         idx.set_coalesce(False)
+        # the same protocol from C threads (no GIL): tools/coalesce_bench.c, built by __graft_entry__.build(), run as
+        # a child process on its own 1M x 1536 index (a pure-C caller of the ABI: svs_index_create + svs_index_search)
+        exe = os.path.join(ROOT, "tools", "coalesce_bench_c")
+        if os.path.exists(exe) and args.dtype == "f32":
+            import subprocess
+            try:
+                r = subprocess.run([exe, str(n_local), str(d), "1.5", str(args.concurrent), "1"], capture_output=True, text=True, timeout=300)
+                for line in r.stdout.splitlines():
+                    if line.startswith("RESULT "):
+                        _, T, mode, qps, lat, qpp = line.split()
+                        concurrent["c_threads"] = {"callers": int(T), "coalesced": float(qps), "coalesced_mean_latency_ms": float(lat),
+                                                   "queries_per_corpus_pass": float(qpp), "note": "pthreads calling svs_index_search(nq = 1), tools/coalesce_bench.c"}
+                if "c_threads" not in concurrent:
+                    concurrent["c_threads"] = {"error": (r.stderr or r.stdout)[-300:]}
+            except Exception as e:   # noqa: BLE001 -- a secondary figure must not sink the bench line
+                concurrent["c_threads"] = {"error": repr(e)[:300]}
 
     # ---- secondary figures (N = 1 only; not `value`): BASELINE.json configs[2] and configs[4], the
     # MFMA-bound batch configurations, each on its own index (synthetic, same recipe as the headline corpus)

@@ -276,6 +276,19 @@ __device__ __forceinline__ f32x4_t pg_lds_read_f32x4(unsigned adr) {
   asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(adr) : "memory");
   return v;
 }
+// the same reads issued without a wait, and the waits that name what they fill (one LDS round trip for a batch of
+// reads instead of one per read: the fp8 epilogue made 16 of them in a row, ~2 k cycles of a 7 k-cycle epilogue)
+__device__ __forceinline__ void pg_lds_issue_f32(float& dst, unsigned adr) { asm volatile("ds_read_b32 %0, %1" : "=v"(dst) : "v"(adr) : "memory"); }
+__device__ __forceinline__ void pg_lds_issue_f32x4(f32x4_t& dst, unsigned adr) { asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(adr) : "memory"); }
+template <int N>
+__device__ __forceinline__ void pg_lds_landed(float (&a)[N]) {
+  static_assert(N == 2 || N == 4, "");
+  if constexpr (N == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])::"memory");
+  else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1])::"memory");
+}
+__device__ __forceinline__ void pg_lds_landed(f32x4_t (&a)[8]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])::"memory");
+}
 __device__ __forceinline__ uint32_t pg_lds_read_u32(unsigned adr) {
   uint32_t v;
   asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(adr) : "memory");
@@ -608,15 +621,20 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
       if constexpr (EB == 1) {   // per-row and per-query dequantisation scales, applied in place (as tg_epilogue: v * (rs * qs))
         // two scores per instruction (v_pk_mul_f32: each half is an ordinary IEEE f32 product, so the bits are those of
         // the scalar form): 128 instead of 256 multiplies per lane
+        float q1[NT];
+        f32x4_t rsv[MT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) pg_lds_issue_f32(q1[j], PG_SIDE_QS + par * 1024 + (wq + j * 16 + r16) * 4);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) pg_lds_issue_f32x4(rsv[i], PG_SIDE_RS + par * 1024 + (lr0 + i * 16) * 4);
+        pg_lds_landed(q1);
+        pg_lds_landed(rsv);
         f32x2_t qs[NT];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const float q = pg_lds_read_f32(PG_SIDE_QS + par * 1024 + (wq + j * 16 + r16) * 4);
-          qs[j] = (f32x2_t){q, q};
-        }
+        for (int j = 0; j < NT; ++j) qs[j] = (f32x2_t){q1[j], q1[j]};
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-          const f32x4_t rs = pg_lds_read_f32x4(PG_SIDE_RS + par * 1024 + (lr0 + i * 16) * 4);
+          const f32x4_t rs = rsv[i];
           const f32x2_t rs01 = {rs[0], rs[1]}, rs23 = {rs[2], rs[3]};
 #pragma unroll
           for (int j = 0; j < NT; ++j) {
@@ -713,9 +731,11 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
         float thr[NT];
         uint32_t base[NT];
 #pragma unroll
+        for (int j = 0; j < NT; ++j) pg_lds_issue_f32(thr[j], PG_SIDE_THR + par * 1024 + (wq + j * 16 + r16) * 4);
+        pg_lds_landed(thr);
+#pragma unroll
         for (int j = 0; j < NT; ++j) {
           const int ql = wq + j * 16 + r16;
-          thr[j] = pg_lds_read_f32(PG_SIDE_THR + par * 1024 + ql * 4);
           // (the last query tile of a batch that is not a whole number of tiles: its padded queries -- zero vectors
           //  -- take no part: nothing reaches +inf but a NaN, and the flush drops those)
           if (t.q0 + ql >= nq) thr[j] = __builtin_inff();
@@ -774,13 +794,15 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
       if (!pair_empty && !general) {
         // (a partly filled last QUERY tile is an interior tile too: the sweeps give its padded queries +inf
         //  thresholds; only the grouped path needs the per-lane query mask, i.e. the general form of pass())
-        bool grouped = last_wcount <= PG_SPARSE_MAX;
-        if (!grouped) grouped = sweep();
-        if (grouped) {
+        const bool few = last_wcount <= PG_SPARSE_MAX;
+        if (few) {
           if (t.q0 + QT <= nq) grouped_full = true;
           else general = true;
-        }
+        } else if (sweep()) general = true;   // (the sweeps found more than the wave's eighth holds: register by register)
       }
+      // (measured and rejected: all 32 groups' compares first, their any-survivor bits folded into one scalar word per
+      //  query column, THEN 32 bit tests -- no compare -> scalar test -> branch chain per group: 8.0 k cycles per tile
+      //  against 7.3 k for this form, profiles/r3_gemm_phased_bench_fp8_grouped_bits.txt)
       if (grouped_full) pass(std::true_type{}, std::true_type{});
       if (general) pass(std::false_type{}, std::false_type{});
       last_wcount = EXP == 32 ? PG_SPARSE_MAX + 1 : wcount;   // (EXP 32: the sweeps on every interior tile, A/B)

@@ -1236,11 +1236,17 @@ int ensure_capacity(svs_index* idx, int64_t rows, bool exact) {
       return fail(SVS_ERR_NOMEM, "hipMalloc(row scales): %s", hipGetErrorString(e));
     }
   }
+  // (the new buffers are the caller's problem only once they are installed: every failure until then frees them)
+  struct Fresh {
+    void* rows; float* scales; bool keep = false;
+    ~Fresh() { if (!keep) { (void)hipFree(rows); (void)hipFree(scales); } }
+  } fresh{nrows, nscales};
   // work already enqueued by the device API may still read the old buffers
   HIP_TRY(hipDeviceSynchronize());
   const int64_t n_old = idx->n;
   if (n_old) HIP_TRY(hipMemcpy(nrows, idx->rows, (size_t)n_old * row_b, hipMemcpyDeviceToDevice));
   if (n_old && nscales) HIP_TRY(hipMemcpy(nscales, idx->row_scales, (size_t)n_old * sizeof(float), hipMemcpyDeviceToDevice));
+  fresh.keep = true;
   (void)hipFree(idx->rows);
   (void)hipFree(idx->row_scales);
   idx->rows = nrows;
@@ -1414,11 +1420,17 @@ int32_t svs_index_staging_acquire(svs_index* idx, float** host_block, int64_t* r
   if (!g.active) {
     const size_t row_b = (size_t)idx->d * sizeof(float);
     g.rows_cap = (int64_t)std::max<size_t>(1, ((size_t)32 << 20) / row_b);
-    HIP_TRY(hipStreamCreateWithFlags(&g.st, hipStreamNonBlocking));
-    for (int i = 0; i < 2; ++i) {
-      HIP_TRY(hipHostMalloc(&g.pin[i], (size_t)g.rows_cap * row_b, hipHostMallocDefault));
-      HIP_TRY(hipEventCreateWithFlags(&g.done[i], hipEventDisableTiming));
-      if (idx->dtype != SVS_DTYPE_F32) HIP_TRY(hipMalloc((void**)&g.dstage[i], (size_t)g.rows_cap * row_b));
+    // (a failure half way through the first-time set-up must not strand the stream and the blocks made so far:
+    //  the next acquire would make them again)
+    hipError_t e = hipStreamCreateWithFlags(&g.st, hipStreamNonBlocking);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+      e = hipHostMalloc(&g.pin[i], (size_t)g.rows_cap * row_b, hipHostMallocDefault);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&g.done[i], hipEventDisableTiming);
+      if (e == hipSuccess && idx->dtype != SVS_DTYPE_F32) e = hipMalloc((void**)&g.dstage[i], (size_t)g.rows_cap * row_b);
+    }
+    if (e != hipSuccess) {
+      staging_free(idx);
+      return fail(e == hipErrorOutOfMemory ? SVS_ERR_NOMEM : SVS_ERR_DEVICE, "staging blocks: %s", hipGetErrorString(e));
     }
     g.cur = 1;
     g.active = true;

@@ -1,7 +1,9 @@
 /* Concurrent single-query callers of the C ABI (tools only): T threads call svs_index_search(nq = 1)
  * back to back for a few seconds, without and with svs_index_set_coalesce.
  *   build: gcc -O2 -I include tools/coalesce_bench.c -o tools/coalesce_bench_c -L svs_amd/lib -lsvs_amd -lpthread -lm -Wl,-rpath,$PWD/svs_amd/lib -Wl,-rpath,/opt/rocm/lib
- *   usage: coalesce_bench_c [rows=1000000] [dim=1536] [seconds=3] */
+ *   usage: coalesce_bench_c [rows=1000000] [dim=1536] [seconds=3] [threads=1,4,16,64,256] [modes=012]
+ *          (modes: 0 solo, 1 coalesced, 2 coalesced without the whole-tile cut; bench.py runs "64 1" and reads the
+ *           RESULT lines) */
 #include <math.h>
 #include <pthread.h>
 #include <stdio.h>
@@ -37,20 +39,27 @@ int main(int argc, char** argv) {
   const long rows = argc > 1 ? atol(argv[1]) : 1000000;
   const int d = argc > 2 ? atoi(argv[2]) : 1536;
   const double secs = argc > 3 ? atof(argv[3]) : 3.0;
-  const int threads[] = {1, 4, 16, 64, 256};
+  int threads[16] = {1, 4, 16, 64, 256}, nthreads = 5;
+  const char* modes = argc > 5 ? argv[5] : "012";
   float* m = (float*)malloc(sizeof(float) * (size_t)rows * d);
   unsigned long long x = 88172645463325252ull;
   size_t i;
   int ti, mode;
   g_d = d;
+  if (argc > 4) {
+    char* p = argv[4];
+    nthreads = 0;
+    while (*p && nthreads < 16) { threads[nthreads] = (int)strtol(p, &p, 10); if (threads[nthreads] > 0 && threads[nthreads] <= 512) ++nthreads; if (*p == ',') ++p; else break; }
+  }
   g_q = (float*)malloc(sizeof(float) * NQ * d);
   if (!m || !g_q) return 2;
   for (i = 0; i < (size_t)rows * d; ++i) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; m[i] = ((float)(x >> 40) / 8388608.0f - 1.0f) * 0.044f; }
   for (i = 0; i < (size_t)NQ * d; ++i) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; g_q[i] = ((float)(x >> 40) / 8388608.0f - 1.0f) * 0.044f; }
   if (svs_index_create(m, rows, d, SVS_DTYPE_F32, 0, 0, &g_idx) != SVS_OK) { fprintf(stderr, "create: %s\n", svs_last_error()); return 4; }
   free(m);
-  for (ti = 0; ti < 5; ++ti)
+  for (ti = 0; ti < nthreads; ++ti)
     for (mode = 0; mode < 3; ++mode) {
+      if (!strchr(modes, '0' + mode)) continue;
       pthread_t th[512];
       const int T = threads[ti];
       long t, total = 0;
@@ -69,6 +78,7 @@ int main(int argc, char** argv) {
       printf("%3d threads %-9s: %9.0f queries/s  (mean latency %.2f ms", T, mode == 0 ? "solo" : (mode == 1 ? "coalesced" : "coal. all"), total / dt, 1e3 * dt * T / (double)total);
       if (mode) printf(", %.1f queries per corpus pass", (double)(q1 - q0) / (double)(p1 - p0 > 0 ? p1 - p0 : 1));
       printf(")\n");
+      printf("RESULT %d %d %.1f %.4f %.2f\n", T, mode, total / dt, 1e3 * dt * T / (double)total, mode ? (double)(q1 - q0) / (double)(p1 - p0 > 0 ? p1 - p0 : 1) : 1.0);
       fflush(stdout);
     }
   svs_index_release(g_idx);
