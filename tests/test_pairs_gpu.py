@@ -105,21 +105,38 @@ def test_tiled_pairs_equal_materialised(gpu, n, d, k, dtype):
 
 
 def _cpu_top_pairs_chunked(md, k, chunk=2000):
-    """Top-k pairs of md.md^T without the n x n matrix: per chunk of query rows keep the pairs
-    that can still make the list, then the reference's order (score desc, flat index desc)."""
+    """Top-k pairs of md.md^T without the n x n matrix (numpy restatement of reference src/svs/util.py:206-233 in
+    chunks of query rows): only columns j > i are formed, a running lower bound (the k-th best so far) filters
+    each chunk with one compare, and the reference's order (score desc, flat index desc) is applied at the end."""
     n = md.shape[0]
-    best = []   # (score, i, j)
+    ks, ki, kj = np.empty(0, np.float32), np.empty(0, np.int64), np.empty(0, np.int64)
+    thr = -np.inf
+
+    def trim(ks, ki, kj):
+        if ks.size <= k:
+            return ks, ki, kj, (-np.inf if ks.size < k else float(ks.min()))
+        order = np.lexsort((-kj, -ki, -ks.astype(np.float64)))[:k]    # score desc, i desc, j desc
+        ks, ki, kj = ks[order], ki[order], kj[order]
+        return ks, ki, kj, float(ks[-1])
+
     for r0 in range(0, n, chunk):
-        s = np.dot(md[r0:r0 + chunk], md.T)
-        ii = np.arange(r0, min(n, r0 + chunk))[:, None]
-        s[np.arange(n)[None, :] <= ii] = -np.inf
-        flat = s.ravel()
-        kk = min(k, flat.size)
-        part = np.argpartition(-flat, kk - 1)[:kk]
-        best += [(float(flat[p]), int(r0 + p // n), int(p % n)) for p in part if np.isfinite(flat[p])]
-        best.sort(key=lambda t: (-t[0], -t[1], -t[2]))
-        best = best[:k]
-    return best
+        r1 = min(n, r0 + chunk)
+        s = np.dot(md[r0:r1], md[r0:].T)                       # columns r0 .. n - 1 only
+        s[:, :r1 - r0][np.tri(r1 - r0, dtype=bool)] = -np.inf   # j <= i inside the diagonal block
+        if not np.isfinite(thr):                               # first chunks: no bound yet, take the chunk's own top k
+            flat = s.ravel()
+            kk = min(k, flat.size)
+            part = np.argpartition(-flat, kk - 1)[:kk]
+            a, c = np.divmod(part, s.shape[1])
+        else:
+            a, c = np.nonzero(s >= thr)
+        v = s[a, c]
+        keep = np.isfinite(v)
+        ks = np.concatenate([ks, v[keep]])
+        ki = np.concatenate([ki, (r0 + a[keep]).astype(np.int64)])
+        kj = np.concatenate([kj, (r0 + c[keep]).astype(np.int64)])
+        ks, ki, kj, thr = trim(ks, ki, kj)
+    return [(float(a), int(b), int(c)) for a, b, c in zip(ks, ki, kj)]
 
 
 @pytest.mark.parametrize("n,d,k,dtype", [(120_000, 128, 200, "f32"), (150_000, 256, 500, "f16"), (70_000, 768, 300, "f16")])   # (the last: phased kernel in pair mode)

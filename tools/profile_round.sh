@@ -13,8 +13,8 @@ run() { local name=$1; shift; rm -rf "$O/prof_${tag}_$name"; rocprofv3 "$@"; ech
 if [[ $part == *a* ]]; then
 # configs[1]: the bench line itself, then HBM bytes of its kernels
 run trace --kernel-trace --stats --output-format csv -d $O/prof_${tag}_trace -- python3 $R/bench.py > $O/prof_${tag}_trace.json
-run fetch --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/prof_${tag}_fetch -- python3 $R/bench.py --no-cpu-baseline --steps 60 --batch "" --concurrent 0 --configs "" > /dev/null
-run write --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/prof_${tag}_write -- python3 $R/bench.py --no-cpu-baseline --steps 60 --batch "" --concurrent 0 --configs "" > /dev/null
+run fetch --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/prof_${tag}_fetch -- python3 $R/bench.py --no-cpu-baseline --steps 60 --batch "" --concurrent 0 --configs "" --kb 0 > /dev/null
+run write --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/prof_${tag}_write -- python3 $R/bench.py --no-cpu-baseline --steps 60 --batch "" --concurrent 0 --configs "" --kb 0 > /dev/null
 # batched f32, 16 queries per call
 run b16_trace --kernel-trace --stats --output-format csv -d $O/prof_${tag}_b16_trace -- python3 $R/tools/prof_batch.py 1000000 1536 f32 16 20 > /dev/null
 run b16_fetch --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/prof_${tag}_b16_fetch -- python3 $R/tools/prof_batch.py 1000000 1536 f32 16 6 > /dev/null
