@@ -335,7 +335,19 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
   const int G = gridDim.x, total = gx * gy;
   // (integer division runs on the vector ALU; whatever hangs on its result -- the loop bounds, the tile
   //  descriptors -- must be told that it is wave-uniform, or it is kept in VGPRs: see tile_desc)
-  const int my_tiles = __builtin_amdgcn_readfirstlane((total - (int)blockIdx.x + G - 1) / G);
+  // kMap (timing experiments 50 / 51, gy == 4 and 256 workgroups only): other workgroup -> tile maps.  The default
+  // (pg_tile_of) gives every XCD, per step, 8 row tiles x the 4 query tiles; 50: 32 row tiles x ONE query tile (its
+  // 768 KiB of queries stay in that XCD's L2; the corpus tile is fetched by four XCDs at the same step: Infinity
+  // Cache); 51: 16 row tiles x 2 query tiles.
+  constexpr int kMap = (EXP == 50 || EXP == 52) ? 1 : (EXP == 51 ? 2 : 0);
+  const bool alt_map = kMap != 0 && gy == 4 && G == 256;
+  int my_tiles_v = (total - (int)blockIdx.x + G - 1) / G;
+  if (alt_map) {
+    const int x = (int)blockIdx.x & 7, c = (int)blockIdx.x >> 3;
+    if (kMap == 1) { const int rset = x >> 2, lim = (gx - rset + 1) / 2; my_tiles_v = lim > c ? (lim - c + 31) / 32 : 0; }
+    else { const int rset = x >> 1, lim = (gx - rset + 3) / 4, cc = c >> 1; my_tiles_v = lim > cc ? (lim - cc + 15) / 16 : 0; }
+  }
+  const int my_tiles = __builtin_amdgcn_readfirstlane(my_tiles_v);
 
   // ---- per-lane constants of the staging side: byte offset of the lane's 16 bytes inside a tile
   // ONE register: the 16 bytes of row li0 = 8 wave + lane / 8 of a tile.  The eight (operand, half, instruction)
@@ -366,6 +378,11 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
     if (j < my_tiles) {
       int bx, by;
       pg_tile_of((int)blockIdx.x + j * G, gx, gy, &bx, &by);
+      if (alt_map) {
+        const int x = (int)blockIdx.x & 7, c = (int)blockIdx.x >> 3;
+        if (kMap == 1) { by = x & 3; bx = (j * 32 + c) * 2 + (x >> 2); }
+        else { by = 2 * (x & 1) + (c & 1); bx = (j * 16 + (c >> 1)) * 4 + (x >> 1); }
+      }
       // (the divisions above run on the vector ALU: without these two, hipcc keeps the descriptors
       //  below in VGPRs and wraps EVERY LDS-DMA instruction in a waterfall loop -- four
       //  v_readfirstlane, two compares, a saveexec and a branch per piece, in among the MFMAs)
@@ -399,7 +416,7 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
                                 : (QT == 256 ? wr * 32 + jj * 128 + (kind >> 1) * 32 : (wave >> 1) * 16 + (kind >> 1) * 16);
     const int vo = tm ? pg_voff(vbase_tm, rows * TG_BKB) : pg_voff(vbase, rows * ldb);
     const unsigned dst = pg_lds_dest<slot * PG_SLOT * 16 + jj * 8192>(wave_lds);
-    if constexpr ((EXP == 20 || EXP == 40 || EXP == 45) && (kind & 1))   // (corpus rows nontemporal: the single-query-tile form, see launch_tiled_eb)
+    if constexpr ((EXP == 20 || EXP == 40 || EXP == 45 || EXP == 52) && (kind & 1))   // (corpus rows nontemporal: the single-query-tile form, see launch_tiled_eb)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(uintptr_t)dst, 16, vo, soff, 0, 2);
     else
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(uintptr_t)dst, 16, vo, soff, 0, 0);

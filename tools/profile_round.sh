@@ -9,7 +9,7 @@ part=${2:-ab}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-run() { local name=$1; shift; rm -rf "$O/prof_${tag}_$name"; rocprofv3 "$@"; echo "[profile_round] $name done"; }
+run() { local name=$1; shift; rm -rf "$O/prof_${tag}_$name"; rocprofv3 "$@"; echo "[profile_round] $name done" >&2; }
 if [[ $part == *a* ]]; then
 # configs[1]: the bench line itself, then HBM bytes of its kernels
 run trace --kernel-trace --stats --output-format csv -d $O/prof_${tag}_trace -- python3 $R/bench.py > $O/prof_${tag}_trace.json
