@@ -202,11 +202,11 @@ __device__ __forceinline__ unsigned pg_slot_base(unsigned adr0) {
   asm volatile("v_add_u32_e32 %0, 0x10000, %1" : "=v"(a) : "v"(adr0));
   return a;
 }
-template <int SLOT>
+template <int SLOT, int MT0 = 0>   // (MT0 = 2: timing experiment 53, only the second half of the fragments is read)
 __device__ __forceinline__ void pg_read_a(u32x4 (&fa)[4][2], const unsigned (&adr)[2]) {
   const unsigned b0 = pg_slot_base<SLOT>(adr[0]), b1 = pg_slot_base<SLOT>(adr[1]);
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
+  for (int mt = MT0; mt < 4; ++mt) {
     PG_DS_READ(fa[mt][0], b0, (SLOT & 3) * 16384 + mt * 2048);
     PG_DS_READ(fa[mt][1], b1, (SLOT & 3) * 16384 + mt * 2048);
   }
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
     if constexpr (kRead) {
       pg_read_b<mine + 0>(fb0, adrB);
       __builtin_amdgcn_sched_barrier(0);
-      pg_read_a<mine + 1>(fa, adrA);
+      pg_read_a<mine + 1, EXP == 53 ? 2 : 0>(fa, adrA);   // (53: what phase 0 would cost with four of its twelve reads elsewhere -- results wrong)
     }
     PG_SYNC_AND_MMA(0, 0, 0, fb0, true, (pg_landed_b(fb0), pg_landed_a(fa)), 3, other + 3, n1, k1);
     // phase 1: B1 in; quadrant (0, 1); stage B0 of the k-tile after next (over this one's B0)

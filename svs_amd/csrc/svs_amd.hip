@@ -17,6 +17,7 @@
 #include <shared_mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "fp8.h"
@@ -682,7 +683,7 @@ int launch_tiled_eb(const svs_index* idx, Ctx* c, int64_t n_rows, int nq, int bn
       // One query tile (up to 256 queries): every corpus byte is used by exactly one workgroup, so its LDS-DMA
       // pieces are issued nontemporal (EXP 20) and leave the L2 to the queries (configs[4]: 7.63 vs 7.89-8.0 ms in
       // tools/gemm_phased_bench; with several query tiles the corpus tile is SHARED through the L2: not there).
-      if (f && nq <= PG_TILE && idx->variant.load() != 9)
+      if (f && (nq <= PG_TILE || idx->variant.load() == 10) && idx->variant.load() != 9)   // (variant 10: nontemporal with several query tiles too, A/B)
         return launch_phased<true, EB, 20>(idx, c, n_rows, nq, scores, sstride, fl, st);
       return f ? launch_phased<true, EB>(idx, c, n_rows, nq, scores, sstride, fl, st)
                : launch_phased<false, EB>(idx, c, n_rows, nq, scores, sstride, fl, st);
@@ -1585,11 +1586,37 @@ static int32_t search_host(svs_index* idx, const float* queries, int32_t nq, int
     c->out_pin_cap = on;
   }
   // queries -> pinned staging -> HBM, in 1 MiB pieces: the DMA of piece i runs under the host copy of
-  // piece i + 1 (a 1024 x 1536 batch is 6.3 MB: ~0.5 ms of memcpy + ~0.13 ms of PCIe back to back)
-  for (size_t off = 0; off < qn; off += (size_t)262144) {
-    const size_t len = std::min((size_t)262144, qn - off);
-    memcpy(c->q_pin + off, queries + off, len * sizeof(float));
-    HIP_TRY(hipMemcpyAsync(c->q_dev + off, c->q_pin + off, len * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  // piece i + 1 (a 1024 x 1536 batch is 6.3 MB: ~0.3 ms of memcpy + ~0.13 ms of PCIe back to back).  From 4 MiB up
+  // a helper thread copies the odd pieces while this one copies the even ones and issues every DMA in order:
+  // the host copy, not the link, was what the staging of a large batch cost.
+  {
+    const size_t piece = 262144;   // floats
+    const size_t npieces = (qn + piece - 1) / piece;
+    std::vector<std::atomic<int>> ready(npieces >= 4 ? npieces : 0);
+    std::thread helper;
+    if (npieces >= 4) {
+      for (auto& r : ready) r.store(0, std::memory_order_relaxed);
+      float* pin = c->q_pin;
+      helper = std::thread([=, &ready] {
+        for (size_t i = 1; i < npieces; i += 2) {
+          const size_t off = i * piece, len = std::min(piece, qn - off);
+          memcpy(pin + off, queries + off, len * sizeof(float));
+          ready[i].store(1, std::memory_order_release);
+        }
+      });
+    }
+    hipError_t herr = hipSuccess;
+    for (size_t i = 0; i < npieces; ++i) {
+      const size_t off = i * piece, len = std::min(piece, qn - off);
+      if (npieces >= 4 && (i & 1)) {
+        while (!ready[i].load(std::memory_order_acquire)) std::this_thread::yield();
+      } else {
+        memcpy(c->q_pin + off, queries + off, len * sizeof(float));
+      }
+      if (herr == hipSuccess) herr = hipMemcpyAsync(c->q_dev + off, c->q_pin + off, len * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    }
+    if (helper.joinable()) helper.join();
+    if (herr != hipSuccess) { (void)hipStreamSynchronize(c->stream); return fail(SVS_ERR_DEVICE, "query upload: %s", hipGetErrorString(herr)); }
   }
   // The final top-k kernel stores its k results straight into the pinned host
   // buffers (device-visible, zero-copy): no D2H copies on the latency path.
@@ -1905,7 +1932,7 @@ int32_t svs_index_get_timing(svs_index* idx, svs_timing_t* out) {
 
 int32_t svs_index_set_variant(svs_index* idx, int32_t variant) {
   if (!idx) return fail(SVS_ERR_INVALID, "null index");
-  if (variant < 0 || variant > 9) return fail(SVS_ERR_INVALID, "unknown variant %d", variant);
+  if (variant < 0 || variant > 10) return fail(SVS_ERR_INVALID, "unknown variant %d", variant);
   idx->variant.store(variant);
   return SVS_OK;
 }

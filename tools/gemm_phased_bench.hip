@@ -133,7 +133,8 @@ int run(int64_t n, int d, int nq, int rounds) {
                   {"phased, tile-major, LDS-DMA + barriers only", launch_phased<EB, 45>},
                   {"phased, XCD map: 32 row tiles x 1 query tile", launch_phased<EB, 50>},
                   {"phased, XCD map: 16 row tiles x 2 query tiles", launch_phased<EB, 51>},
-                  {"phased, XCD map 32 x 1, corpus nontemporal", launch_phased<EB, 52>}};
+                  {"phased, XCD map 32 x 1, corpus nontemporal", launch_phased<EB, 52>},
+                  {"phased, phase 0 reads 8 fragments instead of 12 (timing only)", launch_phased<EB, 53>}};
 #endif
   const int NVALL = sizeof(vs) / sizeof(vs[0]);
   const char* only = getenv("PGB_ONLY");          // e.g. PGB_ONLY=2 runs variant 2 alone (fault hunting)
