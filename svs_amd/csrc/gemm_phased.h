@@ -512,7 +512,7 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
 #define PG_SYNC_AND_MMA(PH, I, J, FB, LGKM8, LAND, KIND, SLOT, NEXT, KT_)    \
   do {                                                                      \
     if constexpr (kStage && !kDmaInMma) stage(PG_C(KIND), PG_C(SLOT), PG_C(NEXT), KT_); \
-    if (LGKM8 && kRead && !kDmaInMma) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");  \
+    if (LGKM8 && kRead && !kDmaInMma) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(EXP == 53 ? 4 : 8) : "memory");  \
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PG_VMCNT_OF(KIND)) : "memory");   \
     PG_STAMP(PH, 0);                                                        \
     __builtin_amdgcn_s_barrier();                                           \

@@ -1586,37 +1586,14 @@ static int32_t search_host(svs_index* idx, const float* queries, int32_t nq, int
     c->out_pin_cap = on;
   }
   // queries -> pinned staging -> HBM, in 1 MiB pieces: the DMA of piece i runs under the host copy of
-  // piece i + 1 (a 1024 x 1536 batch is 6.3 MB: ~0.3 ms of memcpy + ~0.13 ms of PCIe back to back).  From 4 MiB up
-  // a helper thread copies the odd pieces while this one copies the even ones and issues every DMA in order:
-  // the host copy, not the link, was what the staging of a large batch cost.
-  {
-    const size_t piece = 262144;   // floats
-    const size_t npieces = (qn + piece - 1) / piece;
-    std::vector<std::atomic<int>> ready(npieces >= 4 ? npieces : 0);
-    std::thread helper;
-    if (npieces >= 4) {
-      for (auto& r : ready) r.store(0, std::memory_order_relaxed);
-      float* pin = c->q_pin;
-      helper = std::thread([=, &ready] {
-        for (size_t i = 1; i < npieces; i += 2) {
-          const size_t off = i * piece, len = std::min(piece, qn - off);
-          memcpy(pin + off, queries + off, len * sizeof(float));
-          ready[i].store(1, std::memory_order_release);
-        }
-      });
-    }
-    hipError_t herr = hipSuccess;
-    for (size_t i = 0; i < npieces; ++i) {
-      const size_t off = i * piece, len = std::min(piece, qn - off);
-      if (npieces >= 4 && (i & 1)) {
-        while (!ready[i].load(std::memory_order_acquire)) std::this_thread::yield();
-      } else {
-        memcpy(c->q_pin + off, queries + off, len * sizeof(float));
-      }
-      if (herr == hipSuccess) herr = hipMemcpyAsync(c->q_dev + off, c->q_pin + off, len * sizeof(float), hipMemcpyHostToDevice, c->stream);
-    }
-    if (helper.joinable()) helper.join();
-    if (herr != hipSuccess) { (void)hipStreamSynchronize(c->stream); return fail(SVS_ERR_DEVICE, "query upload: %s", hipGetErrorString(herr)); }
+  // piece i + 1 (a 1024 x 1536 batch is 6.3 MB: ~0.3 ms of memcpy + ~0.13 ms of PCIe back to back).
+  // (Measured and dropped in round 3: a helper thread copying the odd pieces while this one copies the even ones --
+  //  the call got 0.35 ms SLOWER, 3.49 vs 3.07-3.12 ms at 1024 x 1536: creating and joining the thread costs more
+  //  than half a host copy saves.)
+  for (size_t off = 0; off < qn; off += (size_t)262144) {
+    const size_t len = std::min((size_t)262144, qn - off);
+    memcpy(c->q_pin + off, queries + off, len * sizeof(float));
+    HIP_TRY(hipMemcpyAsync(c->q_dev + off, c->q_pin + off, len * sizeof(float), hipMemcpyHostToDevice, c->stream));
   }
   // The final top-k kernel stores its k results straight into the pinned host
   // buffers (device-visible, zero-copy): no D2H copies on the latency path.
