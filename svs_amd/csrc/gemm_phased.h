@@ -1,4 +1,4 @@
-// Batched score stage, MFMA-bound panels (256 queries x 256 corpus rows per workgroup):
+// Batched score stage, panels of 256 (or, QT = 128, 128) queries x 256 corpus rows per workgroup:
 //     S[j][i] = sum_d M[i,d] * Q[j,d]      f16 (EB = 2) or e4m3 (EB = 1) operands, f32 accumulate
 // for BASELINE.json configs[2] (1M x 1536 f16, 1024 queries per call) and configs[4]
 // (10M x 3072 fp8, 256 queries per call).  Same arithmetic, k order, LDS image, swizzle and

@@ -17,8 +17,8 @@ for c in range(cases):
     kt = int(rng.choice([6, 8, 10, 12, 14, 16, 20, 24, 32, 48]))
     d = kt * 128 // (2 if dtype == "f16" else 1)
     n = int(rng.integers(131_072, 420_000))
-    nq = int(rng.choice([129, 200, 255, 256, 257, 300, 511, 512, 700, 1024, 1100]))
-    k = int(rng.choice([1, 10, 100, 256]))
+    nq = int(rng.choice([65, 66, 97, 127, 128, 129, 200, 255, 256, 257, 300, 511, 512, 700, 1024, 1100]))   # 65 .. 128: the 128-query tiles
+    k = int(rng.choice([1, 3, 10, 100, 256]))   # (small k: few survivors per tile, the grouped epilogue path)
     if int(rng.integers(4)) == 0:
         n = int(rng.integers(3000, 60_000))          # materialised path (n < 131,072): the non-fused phased kernel
     g = torch.Generator(device=dev); g.manual_seed(1000 + c)
