@@ -12,4 +12,4 @@ from .kb import KB, AsyncKB  # noqa: F401
 from .matrix import DeviceEmbeddingsMatrix, attach  # noqa: F401
 from .multi import MultiDeviceIndex  # noqa: F401
 
-__version__ = "0.2.0"
+__version__ = "0.3.0"

@@ -1306,7 +1306,7 @@ int create_common(int64_t n, int32_t d, int32_t store_dtype, int32_t device, int
 
 extern "C" {
 
-const char* svs_version(void) { return "svs_amd 0.2.0 (gfx950)"; }
+const char* svs_version(void) { return "svs_amd 0.3.0 (gfx950)"; }
 const char* svs_last_error(void) { return g_err.c_str(); }
 // (multi.hip: carries a worker thread's message over to the caller's thread; not part of the ABI)
 int32_t svs_internal_set_error(int32_t code, const char* msg) { return fail(code, "%s", msg ? msg : ""); }
