@@ -2,7 +2,7 @@
 # Regenerates the rocprofv3 evidence under gpurun_out/prof_<tag>_* (run on the GPU box through
 # gpurun, from the repo root); tools/summarize_prof.py / summarize_cfg.py then condense it into
 # profiles/.  Counters are collected in their own passes, with --kernel-trace only.
-#   usage: tools/profile_round.sh r1 [a|b|c|ab]   (a: configs[1], batch-16;  c: configs[2];  b: configs[4])
+#   usage: tools/profile_round.sh r1 [a|b|c|q|ab]   (a: configs[1], batch-16;  c: configs[2];  b: configs[4];  q: 128-query panels)
 set -e -o pipefail
 tag=${1:-r1}
 part=${2:-ab}
@@ -30,5 +30,14 @@ if [[ $part == *b* ]]; then
 run cfg4_trace --kernel-trace --stats --output-format csv -d $O/prof_${tag}_cfg4_trace -- python3 $R/tools/prof_batch.py 10000000 3072 fp8 256 12 > /dev/null
 run cfg4_fetch --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/prof_${tag}_cfg4_fetch -- python3 $R/tools/prof_batch.py 10000000 3072 fp8 256 3 > /dev/null
 run cfg4_pmc --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CU_CYCLES --output-format csv -d $O/prof_${tag}_cfg4_pmc -- python3 $R/tools/prof_batch.py 10000000 3072 fp8 256 2 > /dev/null
+fi
+
+if [[ $part == *q* ]]; then
+# panels of 128 queries over f16 / fp8 (gemm_phased_kernel<.., QT = 128>)
+for dt in f16 fp8; do
+run q128_${dt}_trace --kernel-trace --stats --output-format csv -d $O/prof_${tag}_q128_${dt}_trace -- python3 $R/tools/prof_batch.py 1000000 1536 $dt 128 24 > /dev/null
+run q128_${dt}_fetch --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/prof_${tag}_q128_${dt}_fetch -- python3 $R/tools/prof_batch.py 1000000 1536 $dt 128 4 > /dev/null
+done
+echo "[profile_round] q passes done"
 fi
 echo "[profile_round] all passes done"
