@@ -17,14 +17,14 @@ using namespace svs;
 struct Args {
   uint8_t *M, *Q; float* S; int64_t n; int ldb, nq; uint32_t* st; uint64_t* cand; float *thr, *rs;
 };
-template <int EB, int EXP>
+template <int EB, int EXP, int QT = 256>
 void launch_phased(const Args& a, int cus) {
   static bool once = false;
-  if (!once) { CK(hipFuncSetAttribute((const void*)gemm_phased_kernel<true, EB, EXP>, hipFuncAttributeMaxDynamicSharedMemorySize, PG_LDS_TOTAL)); once = true; }
-  const int gx = (int)((a.n + 255) / 256), gy = (a.nq + 255) / 256;
+  if (!once) { CK(hipFuncSetAttribute((const void*)gemm_phased_kernel<true, EB, EXP, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, PG_LDS_TOTAL)); once = true; }
+  const int gx = (int)((a.n + 255) / 256), gy = (a.nq + QT - 1) / QT;
   const unsigned grid = (unsigned)std::min<int64_t>((int64_t)gx * gy, cus);
   if (getenv("PGB_REAL")) CK(hipMemsetAsync(a.st, 0, (size_t)a.nq * SCR_WORDS * 4, 0));   // (the candidate lists start empty, like in a search)
-  hipLaunchKernelGGL((gemm_phased_kernel<true, EB, EXP>), dim3(grid), dim3(PG_THREADS), PG_LDS_TOTAL, 0, a.M, a.Q, a.S, a.n, a.ldb, a.n, a.nq, gx, gy,
+  hipLaunchKernelGGL((gemm_phased_kernel<true, EB, EXP, QT>), dim3(grid), dim3(PG_THREADS), PG_LDS_TOTAL, 0, a.M, a.Q, a.S, a.n, a.ldb, a.n, a.nq, gx, gy,
                      a.st, (int)SCR_WORDS, a.cand, (uint32_t)CAND_CAP, a.thr, 1, a.rs, a.rs);
 }
 template <int EB>
@@ -121,7 +121,11 @@ int run(int64_t n, int d, int nq, int rounds) {
   CK(hipDeviceSynchronize());
   typedef void (*Fn)(const Args&, int);
   struct V { const char* name; Fn fn; };
-#ifdef PGB_FULL   // every ablation (slow to compile: fourteen instantiations per operand type)
+#ifdef PGB_Q128   // panels of up to 128 queries: the 128-query tiles (run with nq <= 128)
+  const V vs[] = {{"round-1 tiled 256x256 (reference only)", launch_tiled<EB>}, {"phased QT=128, corpus nontemporal (what ships)", launch_phased<EB, 20, 128>},
+                  {"phased QT=128, default policy", launch_phased<EB, 0, 128>}, {"phased QT=128, no epilogue", launch_phased<EB, 14, 128>},
+                  {"phased QT=128, LDS-DMA + barriers only", launch_phased<EB, 5, 128>}, {"phased QT=128, tile-major, LDS-DMA + barriers only", launch_phased<EB, 45, 128>}};
+#elif defined(PGB_FULL)   // every ablation (slow to compile: fourteen instantiations per operand type)
   const V vs[] = {{"round-1 tiled 256x256", launch_tiled<EB>}, {"phased", launch_phased<EB, 0>}, {"phased, no LDS-DMA in loop", launch_phased<EB, 1>},
                   {"phased, no fragment reads", launch_phased<EB, 2>}, {"phased, no MFMA", launch_phased<EB, 3>},
                   {"phased, no stagger", launch_phased<EB, 7>}, {"phased, LDS-DMA + barriers only", launch_phased<EB, 5>}, {"phased, DMA pieces between the MFMAs", launch_phased<EB, 30>}, {"phased, always k-tile 0 (L2 hits)", launch_phased<EB, 21>}, {"phased, DMA + barriers only, always k-tile 0", launch_phased<EB, 25>}, {"phased, barriers only", launch_phased<EB, 26>}, {"phased, epilogue with a branch per register", launch_phased<EB, 31>}, {"phased, corpus pieces nontemporal", launch_phased<EB, 20>}, {"phased, no epilogue", launch_phased<EB, 14>}};
