@@ -197,7 +197,9 @@ int32_t svs_index_search_device(svs_index* idx, const float* dev_queries, int32_
                                 int32_t* out_count, void* hip_stream);
 
 /* All scores of one query, f32 (n) to host: the raw `np.dot(M, q)` vector
- * (src/svs/kb.py:1623) for callers that want it and for parity tests. */
+ * (src/svs/kb.py:1623) for callers that want it and for parity tests.  out_scores must hold
+ * one float per row the handle holds WHEN THE CALL RUNS (svs_index_info().n): size it after the last
+ * svs_index_append / svs_index_staging_commit, and do not grow the index from another thread meanwhile. */
 int32_t svs_index_scores(svs_index* idx, const float* query, int32_t d, float* out_scores);
 
 /* ---- pairwise: replaces np.dot(M, M.T) + get_top_pairs of
