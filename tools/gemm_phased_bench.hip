@@ -104,7 +104,7 @@ int run(int64_t n, int d, int nq, int rounds) {
   {
     // the threshold the prefix pass would hand the epilogue: the k-th best (k = 100) of max(16384, n / 64) rows,
     // in sigmas of the score distribution (2.49 at a 16,384-row prefix, 3.22 at configs[4]'s 156,250)
-    const double prefix = std::max(16384.0, (double)n / 64.0), p = 100.0 / prefix;
+    const double prefix = getenv("PGB_PREFIX") ? atof(getenv("PGB_PREFIX")) : std::max(16384.0, (double)n / 64.0), p = 100.0 / prefix;   // (PGB_PREFIX: thresholds as tight as a prefix of that many rows would give)
     const double t = sqrt(-2.0 * log(p)), z = t - (2.515517 + 0.802853 * t + 0.010328 * t * t) / (1.0 + 1.432788 * t + 0.189269 * t * t + 0.001308 * t * t * t);
     printf("thresholds: %.2f sigma (prefix %.0f rows)\n", z, prefix);
     std::vector<float> th(nq, real ? (float)z / sqrtf((float)d) : 1e30f); CK(hipMemcpy(a.thr, th.data(), nq * 4, hipMemcpyHostToDevice));
