@@ -261,7 +261,8 @@ constexpr int PG_SIDE_CNT = PG_SIDE_QS + 2048;          // u32 [2][8]: candidate
 constexpr int PG_SIDE_KEY = PG_SIDE_CNT + 64;           // u32 [2][PG_PARK][2]: (score bits, code); wave w owns entries [w * PG_PARK / 8, ..)
 constexpr int PG_LDS_TOTAL = PG_SIDE_KEY + 2 * PG_PARK * 8;  // 153,664 bytes of the 163,840
 // a parked candidate's code: row inside the tile (8 bits) | query inside the tile << 8
-constexpr int PG_SPARSE_MAX = 8;   // survivors per wave and tile up to which the epilogue compares-and-branches per group of four registers
+constexpr int PG_SPARSE_MAX = 16;  // survivors per wave and tile up to which the epilogue compares-and-branches per group of four registers
+                                   // (~150 cycles per group that holds one: at 16 still below the sweeps' fixed 10-11 k cycles per tile)
 constexpr int PG_FLUSH_KT = 2, PG_MIN_KT = 6;   // the flush brackets k-tiles 2 and 3 of the next tile
 
 // LDS accesses of the epilogue / flush: inline asm, so that hipcc neither orders them against the
