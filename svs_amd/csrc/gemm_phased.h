@@ -364,6 +364,7 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
     const int li0 = 8 * wave + (lane >> 3), pc = lane & 7;
     vbase = li0 * ldb + (pc ^ tg_swz(li0)) * 16;
     if constexpr (EXP == 40 || EXP == 45) vbase_tm = li0 * TG_BKB + (pc ^ tg_swz(li0)) * 16;
+    if constexpr (EXP == 41 || EXP == 46) vbase_tm = wave * 8 * ldb + (lane >> 3) * TG_BKB + (pc ^ tg_swz(li0)) * 16;   // (group `wave` of the half-tile; the piece's rows are whole groups)
   }
   // ---- ... and of the reading side: LDS byte address of the lane's 16 bytes in slot 0 / slot 4
   // (pg_read_a / pg_read_b)
@@ -410,14 +411,15 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
     constexpr int kind = decltype(KIND)::value, slot = decltype(SLOT)::value, jj = decltype(JJ)::value;
     constexpr bool next = decltype(NEXT)::value != 0;
     constexpr bool tm = (EXP == 40 || EXP == 45) && (kind & 1);   // (timing-only: the corpus addressed as if tile-major -- a k-tile of a row tile one contiguous 32 KiB block)
-    const int soff = (EXP == 21 || EXP == 25) ? 0 : (tm ? kt * (PG_TILE * TG_BKB) : kt * TG_BKB);   // (ablation 21: always the first k-tile: L2 hits)
+    constexpr bool il = (EXP == 41 || EXP == 46) && (kind & 1);   // (timing-only: as if 8-row-interleaved -- every 1 KiB piece contiguous, a group of 8 rows k-tile by k-tile)
+    const int soff = (EXP == 21 || EXP == 25) ? 0 : (tm ? kt * (PG_TILE * TG_BKB) : (il ? kt * 1024 : kt * TG_BKB));   // (ablation 21: always the first k-tile: L2 hits)
     const __amdgpu_buffer_rsrc_t rs = (kind & 1) ? (next ? nxt.a : cur.a) : (next ? nxt.b : cur.b);
     // B, QT = 128: half-tile row li = li0 (0 .. 63) holds query (li >> 4) * 32 + h * 16 + (li & 15) = li0 + (wave >> 1) * 16 + h * 16
     const int rows = (kind & 1) ? jj * 128 + (kind >> 1) * 64
                                 : (QT == 256 ? wr * 32 + jj * 128 + (kind >> 1) * 32 : (wave >> 1) * 16 + (kind >> 1) * 16);
-    const int vo = tm ? pg_voff(vbase_tm, rows * TG_BKB) : pg_voff(vbase, rows * ldb);
+    const int vo = tm ? pg_voff(vbase_tm, rows * TG_BKB) : pg_voff(il ? vbase_tm : vbase, rows * ldb);
     const unsigned dst = pg_lds_dest<slot * PG_SLOT * 16 + jj * 8192>(wave_lds);
-    if constexpr ((EXP == 20 || EXP == 40 || EXP == 45 || EXP == 52) && (kind & 1))   // (corpus rows nontemporal: the single-query-tile form, see launch_tiled_eb)
+    if constexpr ((EXP == 20 || EXP == 40 || EXP == 45 || EXP == 52 || EXP == 41 || EXP == 46) && (kind & 1))   // (corpus rows nontemporal: the single-query-tile form, see launch_tiled_eb)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(uintptr_t)dst, 16, vo, soff, 0, 2);
     else
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(uintptr_t)dst, 16, vo, soff, 0, 0);
@@ -455,7 +457,7 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
 
   f32x4_t acc[MT][NT];
   u32x4 fa[4][2], fb0[NTQ][2], fb1[NTQ][2];
-  if constexpr (EXP == 2 || EXP == 5 || EXP == 25 || EXP == 26 || EXP == 45) {   // (ablation without fragment reads: defined operands)
+  if constexpr (EXP == 2 || EXP == 5 || EXP == 25 || EXP == 26 || EXP == 45 || EXP == 46) {   // (ablation without fragment reads: defined operands)
     const u32x4 c = {0x3c003c00u + (uint32_t)lane, 0x3c003c00u, 0x38003800u, 0x3c003c00u};
 #pragma unroll
     for (int i = 0; i < 4; ++i) fa[i][0] = fa[i][1] = c;
@@ -506,7 +508,7 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
     }
   };
 #define PG_C(v) std::integral_constant<int, (v)>{}
-  constexpr bool kStage = EXP != 1 && EXP != 26, kRead = EXP != 2 && EXP != 5 && EXP != 25 && EXP != 26 && EXP != 45, kMma = EXP != 3 && EXP != 5 && EXP != 25 && EXP != 26 && EXP != 45;   // (45: tile-major corpus, DMA + barriers only)   // (26: barriers only)   // (EXP 5: LDS-DMA and barriers only)
+  constexpr bool kStage = EXP != 1 && EXP != 26, kRead = EXP != 2 && EXP != 5 && EXP != 25 && EXP != 26 && EXP != 45 && EXP != 46, kMma = EXP != 3 && EXP != 5 && EXP != 25 && EXP != 26 && EXP != 45 && EXP != 46;   // (45: tile-major corpus, DMA + barriers only)   // (26: barriers only)   // (EXP 5: LDS-DMA and barriers only)
   constexpr bool kDmaInMma = (PG_DMA_IN_MMA != 0) != (EXP == 30);   // (EXP 30: the other placement, A/B)
   // what follows the loads of a phase: [retire the B reads] wait for the NEXT phase's data, barrier,
   // fragments in, 16 MFMAs at raised priority (keeps hipcc from moving them over the barriers), barrier

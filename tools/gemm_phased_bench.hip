@@ -124,7 +124,8 @@ int run(int64_t n, int d, int nq, int rounds) {
 #ifdef PGB_Q128   // panels of up to 128 queries: the 128-query tiles (run with nq <= 128)
   const V vs[] = {{"round-1 tiled 256x256 (reference only)", launch_tiled<EB>}, {"phased QT=128, corpus nontemporal (what ships)", launch_phased<EB, 20, 128>},
                   {"phased QT=128, default policy", launch_phased<EB, 0, 128>}, {"phased QT=128, no epilogue", launch_phased<EB, 14, 128>},
-                  {"phased QT=128, LDS-DMA + barriers only", launch_phased<EB, 5, 128>}, {"phased QT=128, tile-major, LDS-DMA + barriers only", launch_phased<EB, 45, 128>}};
+                  {"phased QT=128, LDS-DMA + barriers only", launch_phased<EB, 5, 128>}, {"phased QT=128, tile-major, LDS-DMA + barriers only", launch_phased<EB, 45, 128>},
+                  {"phased QT=128, 8-row-interleaved image (timing only)", launch_phased<EB, 41, 128>}, {"phased QT=128, 8-row-interleaved, LDS-DMA + barriers only", launch_phased<EB, 46, 128>}};
 #elif defined(PGB_FULL)   // every ablation (slow to compile: fourteen instantiations per operand type)
   const V vs[] = {{"round-1 tiled 256x256", launch_tiled<EB>}, {"phased", launch_phased<EB, 0>}, {"phased, no LDS-DMA in loop", launch_phased<EB, 1>},
                   {"phased, no fragment reads", launch_phased<EB, 2>}, {"phased, no MFMA", launch_phased<EB, 3>},
@@ -138,7 +139,8 @@ int run(int64_t n, int d, int nq, int rounds) {
                   {"phased, XCD map: 32 row tiles x 1 query tile", launch_phased<EB, 50>},
                   {"phased, XCD map: 16 row tiles x 2 query tiles", launch_phased<EB, 51>},
                   {"phased, XCD map 32 x 1, corpus nontemporal", launch_phased<EB, 52>},
-                  {"phased, phase 0 reads 8 fragments instead of 12 (timing only)", launch_phased<EB, 53>}};
+                  {"phased, phase 0 reads 8 fragments instead of 12 (timing only)", launch_phased<EB, 53>},
+                  {"phased, nt, 8-row-interleaved image (timing only)", launch_phased<EB, 41>}, {"phased, 8-row-interleaved, LDS-DMA + barriers only", launch_phased<EB, 46>}};
 #endif
   const int NVALL = sizeof(vs) / sizeof(vs[0]);
   const char* only = getenv("PGB_ONLY");          // e.g. PGB_ONLY=2 runs variant 2 alone (fault hunting)

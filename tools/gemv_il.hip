@@ -14,6 +14,45 @@
 using namespace svs;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
+// the same with the lane's NK query chunks held in registers (no LDS, no barrier); NT: nontemporal loads
+template <int NK, int WPB, int UB, bool NT>
+__global__ __launch_bounds__(WPB * 64) void gemv_f16_il_regq_kernel(const u32x4* __restrict__ M, const u32x4* __restrict__ qh, float* __restrict__ scores, int64_t n) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t group = (int64_t)blockIdx.x * WPB + wave;
+  if (group * 8 >= n) return;
+  const u32x4* p = M + group * (NK * 64) + lane;
+  u32x4 buf[UB];
+#pragma unroll
+  for (int j = 0; j < UB; ++j) buf[j] = NT ? __builtin_nontemporal_load(p + j * 64) : p[j * 64];
+  u32x4 qv[NK];
+#pragma unroll
+  for (int k = 0; k < NK; ++k) qv[k] = qh[k * 8 + (lane & 7)];
+  float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+  for (int k0 = 0; k0 < NK; k0 += UB) {
+    u32x4 nxt[UB];
+    if (k0 + UB < NK) {
+#pragma unroll
+      for (int j = 0; j < UB; ++j) nxt[j] = NT ? __builtin_nontemporal_load(p + (k0 + UB + j) * 64) : p[(k0 + UB + j) * 64];
+    }
+#pragma unroll
+    for (int j = 0; j < UB; ++j) {
+      if (j & 1) s1 = dot8(buf[j], qv[k0 + j], s1); else s0 = dot8(buf[j], qv[k0 + j], s0);
+    }
+    if (k0 + UB < NK) {
+#pragma unroll
+      for (int j = 0; j < UB; ++j) buf[j] = nxt[j];
+    }
+  }
+  float s = s0 + s1;
+  s += __shfl_xor(s, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  s += __shfl_xor(s, 4, 64);
+  const int64_t row = group * 8 + (lane >> 3);
+  if ((lane & 7) == 0 && row < n) scores[row] = s;
+}
+
 template <int NK, int WPB, int UB>   // UB: loads issued per batch
 __global__ __launch_bounds__(WPB * 64) void gemv_f16_il_kernel(const u32x4* __restrict__ M, const u32x4* __restrict__ qh, float* __restrict__ scores, int64_t n) {
   __shared__ u32x4 qs[NK * 8];
@@ -68,5 +107,10 @@ int main(int argc, char** argv) {
   timeit("interleaved, 16 waves, 24 loads per batch", [&] { hipLaunchKernelGGL((gemv_f16_il_kernel<24, 16, 24>), dim3((unsigned)((n / 8 + 15) / 16)), dim3(1024), 0, 0, (const u32x4*)M, (const u32x4*)qh, sc, n); });
   timeit("interleaved, 8 waves, 12 loads per batch", [&] { hipLaunchKernelGGL((gemv_f16_il_kernel<24, 8, 12>), dim3((unsigned)((n / 8 + 7) / 8)), dim3(512), 0, 0, (const u32x4*)M, (const u32x4*)qh, sc, n); });
   timeit("interleaved, 4 waves, 12 loads per batch", [&] { hipLaunchKernelGGL((gemv_f16_il_kernel<24, 4, 12>), dim3((unsigned)((n / 8 + 3) / 4)), dim3(256), 0, 0, (const u32x4*)M, (const u32x4*)qh, sc, n); });
+  timeit("interleaved, query in registers, 16 waves, 12 loads in flight, nt", [&] { hipLaunchKernelGGL((gemv_f16_il_regq_kernel<24, 16, 12, true>), dim3((unsigned)((n / 8 + 15) / 16)), dim3(1024), 0, 0, (const u32x4*)M, (const u32x4*)qh, sc, n); });
+  timeit("interleaved, query in registers, 16 waves, 6 loads in flight, nt", [&] { hipLaunchKernelGGL((gemv_f16_il_regq_kernel<24, 16, 6, true>), dim3((unsigned)((n / 8 + 15) / 16)), dim3(1024), 0, 0, (const u32x4*)M, (const u32x4*)qh, sc, n); });
+  timeit("interleaved, query in registers, 8 waves, 12 loads in flight, nt", [&] { hipLaunchKernelGGL((gemv_f16_il_regq_kernel<24, 8, 12, true>), dim3((unsigned)((n / 8 + 7) / 8)), dim3(512), 0, 0, (const u32x4*)M, (const u32x4*)qh, sc, n); });
+  timeit("interleaved, query in registers, 16 waves, 12 loads in flight, default policy", [&] { hipLaunchKernelGGL((gemv_f16_il_regq_kernel<24, 16, 12, false>), dim3((unsigned)((n / 8 + 15) / 16)), dim3(1024), 0, 0, (const u32x4*)M, (const u32x4*)qh, sc, n); });
+  timeit("row-major again", [&] { hipLaunchKernelGGL((gemv_f16_oneshot_kernel<3, 2, 16>), dim3((unsigned)((n + 31) / 32)), dim3(1024), 0, 0, (const u32x4*)M, (const v4f*)qf, sc, n); });
   return 0;
 }
