@@ -176,16 +176,12 @@ int32_t svs_index_search(svs_index* idx, const float* queries, int32_t nq, int32
  * (the batched kernels sum in another order, far inside 1e-5): two rows whose scores are closer than that
  * rounding noise may therefore come out swapped, exactly as between two runs of numpy's own sgemv with
  * different blocking (hard part 1).  On every golden corpus recorded from the reference the
- * coalesced rows equal the reference's position by position (tests/test_coalesce.py).  Errors stay with the
+ * coalesced rows equal the reference's position by position (tests/test_search_gpu.py::test_search_golden).  Errors stay with the
  * call that made them.  svs_index_coalesce_stats: passes made / queries answered through this path;
  * svs_index_coalesce_sizes: out[s] = passes that carried exactly s queries, s < cap (cap <= 257). */
 int32_t svs_index_set_coalesce(svs_index* idx, int32_t enable);
 int32_t svs_index_coalesce_stats(svs_index* idx, int64_t* passes, int64_t* queries);
 int32_t svs_index_coalesce_sizes(svs_index* idx, int64_t* out, int32_t cap);
-/* Tests and benchmarks: the NEXT coalesced pass waits (at most 5 s) until n single-query calls are queued,
- * so that a pass of a chosen size can be formed on purpose; one shot, 0 cancels. */
-int32_t svs_index_coalesce_hold(svs_index* idx, int32_t n);
-
 /* Device-resident variant for pipelines and the multi-GPU gather (8(e)): queries
  * and outputs are device pointers on the index's device, work is enqueued on
  * `hip_stream` (a hipStream_t; NULL = the default stream) and the call returns
@@ -197,10 +193,16 @@ int32_t svs_index_search_device(svs_index* idx, const float* dev_queries, int32_
                                 int32_t* out_count, void* hip_stream);
 
 /* All scores of one query, f32 (n) to host: the raw `np.dot(M, q)` vector
- * (src/svs/kb.py:1623) for callers that want it and for parity tests.  out_scores must hold
- * one float per row the handle holds WHEN THE CALL RUNS (svs_index_info().n): size it after the last
- * svs_index_append / svs_index_staging_commit, and do not grow the index from another thread meanwhile. */
-int32_t svs_index_scores(svs_index* idx, const float* query, int32_t d, float* out_scores);
+ * (src/svs/kb.py:1623) for callers that want it and for parity tests.  The call writes one float per
+ * row the handle holds WHEN IT RUNS and never more than out_capacity: a handle that has grown past the
+ * caller's buffer (svs_index_append / svs_index_staging_commit from another thread between sizing the
+ * buffer and this call) is SVS_ERR_INVALID, not an overflow -- the row count is read under the same
+ * lock that appends take exclusively.  *out_n (may be NULL) = the rows the handle holds, written in
+ * every case, so a caller can re-size and retry.  (Replaces round 3's svs_index_scores(idx, q, d, out),
+ * which had no capacity and overflowed the caller's heap in exactly that race; the old symbol is gone
+ * on purpose: a stale binding fails at load time instead of corrupting memory.) */
+int32_t svs_index_scores_n(svs_index* idx, const float* query, int32_t d, float* out_scores,
+                           int64_t out_capacity, int64_t* out_n);
 
 /* ---- pairwise: replaces np.dot(M, M.T) + get_top_pairs of
  *      document_top_pairwise_scores, src/svs/kb.py:1642-1671, src/svs/util.py:206-233 --

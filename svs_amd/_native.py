@@ -65,7 +65,6 @@ SIGNATURES = {
     "svs_index_set_coalesce": (C.c_int32, [_P, C.c_int32]),
     "svs_index_coalesce_stats": (C.c_int32, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "svs_index_coalesce_sizes": (C.c_int32, [_P, C.POINTER(C.c_int64), C.c_int32]),
-    "svs_index_coalesce_hold": (C.c_int32, [_P, C.c_int32]),
     "svs_multi_create": (C.c_int32, [_P, C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.POINTER(_P)]),
     "svs_multi_search": (C.c_int32, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.POINTER(C.c_int32)]),
     "svs_multi_retain": (C.c_int32, [_P]),
@@ -80,13 +79,19 @@ SIGNATURES = {
     "svs_index_info": (C.c_int32, [_P, C.POINTER(IndexInfo)]),
     "svs_index_search": (C.c_int32, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.POINTER(C.c_int32)]),
     "svs_index_search_device": (C.c_int32, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.POINTER(C.c_int32), _P]),
-    "svs_index_scores": (C.c_int32, [_P, _P, C.c_int32, _P]),
+    "svs_index_scores_n": (C.c_int32, [_P, _P, C.c_int32, _P, C.c_int64, C.POINTER(C.c_int64)]),
     "svs_index_top_pairs": (C.c_int32, [_P, C.c_int32, _P, _P, _P, C.POINTER(C.c_int32)]),
     "svs_index_debug_dequant": (C.c_int32, [_P, C.c_int64, C.c_int64, _P]),
     "svs_index_debug_query": (C.c_int32, [_P, _P, C.c_int32, _P]),
     "svs_index_set_timing": (C.c_int32, [_P, C.c_int32]),
     "svs_index_get_timing": (C.c_int32, [_P, C.POINTER(Timing)]),
     "svs_index_set_variant": (C.c_int32, [_P, C.c_int32]),
+}
+
+# svs_amd/csrc/internal.h: hooks for this repo's own tests, tools and bench (not part of the boundary)
+INTERNAL = {
+    "svs_internal_coalesce_hold": (C.c_int32, [_P, C.c_int32]),
+    "svs_internal_tune": (C.c_int32, [C.c_int32, C.c_int64]),
 }
 
 _lib: Optional[C.CDLL] = None
@@ -132,7 +137,7 @@ def load() -> C.CDLL:
         )
     _share_torch_hip_runtime()
     lib = C.CDLL(_LIB_PATH)  # CDLL releases the GIL around every call
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in list(SIGNATURES.items()) + list(INTERNAL.items()):
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args

@@ -44,7 +44,7 @@ constexpr int FA_THREADS = 512;   // histogram / filter workgroup
 constexpr int SORT_THREADS = 1024;  // global bitonic sort (path B) workgroup
 constexpr int FINAL_THREADS = 256;  // final kernel workgroup
 constexpr int RS_BINS = 2048;     // in-LDS radix select: 11 bits per pass
-constexpr int PICK_MAX_PER = 8;
+constexpr int PICK_MAX_PER = 16;
 
 // per-query scratch: SelHeader followed by WBINS histogram words (all zero between searches)
 struct SelHeader {
@@ -61,14 +61,19 @@ __device__ __forceinline__ int window_bin(uint32_t key32) {
 }
 
 // The first ACT threads of a workgroup find, from a histogram of `bins` buckets
-// (bins / ACT <= 8), the bucket holding the k_rem-th largest element counting
+// (bins / ACT <= PICK_MAX_PER), the bucket holding the k_rem-th largest element counting
 // from the top.  *b_out = bucket (0xffffffff if the histogram holds fewer than
 // k_rem elements), *k_out = rank inside it (1-based from the bucket's top).
 // Every thread of the workgroup must call this (workgroup barriers inside);
 // `sh` is ACT+2 words of LDS.
+// The scan over the per-thread sums runs inside each wave on cross-lane moves (no LDS, no barrier)
+// and meets the other waves' totals once: three workgroup barriers per call where the Hillis-Steele
+// scan over LDS took 2 log2(ACT) + 3 (every workgroup of the filter kernel and every radix pass of the
+// final / k-th-value kernels pays for this call).
 template <int ACT>
 __device__ __forceinline__ void pick_bucket(const uint32_t* hist, int bins, uint32_t k_rem,
                                             uint32_t* sh, uint32_t* b_out, uint32_t* k_out) {
+  static_assert(ACT % 64 == 0 && ACT / 64 <= 16, "whole waves");
   const int tid = threadIdx.x;
   const bool act = tid < ACT;
   const int per = bins / ACT;
@@ -81,18 +86,19 @@ __device__ __forceinline__ void pick_bucket(const uint32_t* hist, int bins, uint
       loc[i] = hist[hi - 1 - i];  // descending bucket order
       sum += loc[i];
     }
-    sh[tid] = sum;
   }
+  const int lane = tid & 63, w = tid >> 6;
+  uint32_t incl = sum;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = (uint32_t)__shfl_up((int)incl, off, 64);
+    if (lane >= off) incl += t;
+  }
+  if (act && lane == 63) sh[w] = incl;
   if (tid == 0) sh[ACT] = 0xffffffffu;
   __syncthreads();
-  for (int off = 1; off < ACT; off <<= 1) {  // inclusive Hillis-Steele scan
-    const uint32_t v = (act && tid >= off) ? sh[tid - off] : 0;
-    __syncthreads();
-    if (act) sh[tid] += v;
-    __syncthreads();
-  }
   if (act) {
-    const uint32_t incl = sh[tid];
+    for (int i = 0; i < w; ++i) incl += sh[i];
     const uint32_t excl = incl - sum;
     if (excl < k_rem && k_rem <= incl) {
       uint32_t c = excl;
@@ -359,6 +365,7 @@ __device__ __forceinline__ uint64_t block_radix_select_regs(const uint64_t (&kr)
   return prefix;
 }
 constexpr int FINAL_REG_KEYS = 32;   // per thread: lists of up to FINAL_THREADS * 32 = 8192 candidates
+constexpr int FINAL_DIRECT = 1024;    // lists this short are sorted as they are
 
 // ---- path A launch 3 / path D.  grid = nq, one workgroup per query ------------
 // mode 0: path A (candidates from the filter); mode 1: path D (n <= SORT_CAP);
@@ -371,7 +378,7 @@ __global__ __launch_bounds__(FINAL_THREADS) void select_final_kernel(
     int64_t row_offset, float* __restrict__ out_scores, int64_t* __restrict__ out_rows,
     const uint32_t* __restrict__ dead_bits = nullptr) {
   __shared__ uint64_t S[SORT_CAP];
-  __shared__ uint32_t lh[RS_BINS];
+  __shared__ uint32_t lh[WBINS];   // window histogram (WBINS) or radix-select histogram (RS_BINS <= WBINS)
   __shared__ uint32_t sh[256 + 2];
   __shared__ uint32_t s_cnt;
   __shared__ uint32_t s_dead;
@@ -419,24 +426,63 @@ __global__ __launch_bounds__(FINAL_THREADS) void select_final_kernel(
       }
       return;
     }
-    if (flag == 0 && n_cand <= (uint32_t)SORT_CAP) {
+    if (flag == 0 && n_cand <= (uint32_t)FINAL_DIRECT) {
       m = next_pow2((int)n_cand < 2 ? 2 : (int)n_cand);
       for (int i = threadIdx.x; i < m; i += blockDim.x) S[i] = i < (int)n_cand ? cq[i] : 0ull;
     } else {
       if (threadIdx.x == 0) s_cnt = 0;
       m = next_pow2(count < 2 ? 2 : count);
-      for (int i = threadIdx.x; i < m; i += blockDim.x) S[i] = 0ull;
       if (flag == 0 && n_cand <= (uint32_t)(FINAL_THREADS * FINAL_REG_KEYS)) {
+        // Lists of up to 8192 candidates (the fused GEMM epilogue leaves ~k n / prefix of them): read ONCE into
+        // registers, then ONE histogram pass over the window bins of the score (128 bins per octave, the binning of
+        // path A's launch 1) finds the bin b* of the count-th best; everything at or above b* -- count plus the few
+        // dozen keys that share b* -- goes to the LDS sort.  (Round 3: five to six 11-bit radix passes over the
+        // 64-bit keys, whose leading bits the candidates of one query all share: most lanes of a wave added to ONE
+        // LDS word per pass, 46-58 % of the kernel's LDS cycles were conflict cycles.)  A window that does not hold
+        // `count` keys (negative or zero scores among the best) or a bin too crowded for the sort falls back to
+        // that radix select on the same registers: always exact.
         uint64_t kr[FINAL_REG_KEYS];
         const int mine = (int)n_cand > (int)threadIdx.x ? ((int)n_cand - (int)threadIdx.x + FINAL_THREADS - 1) / FINAL_THREADS : 0;
 #pragma unroll
         for (int j = 0; j < FINAL_REG_KEYS; ++j) kr[j] = j < mine ? cq[threadIdx.x + j * FINAL_THREADS] : 0ull;
-        __syncthreads();   // s_cnt = 0 and the cleared S are visible
-        const uint64_t T = block_radix_select_regs(kr, mine, (uint32_t)count, lh, sh);
+        for (int i = threadIdx.x; i < WBINS; i += blockDim.x) lh[i] = 0;
+        __syncthreads();   // s_cnt = 0 and the cleared histogram are visible
 #pragma unroll
-        for (int j = 0; j < FINAL_REG_KEYS; ++j)
-          if (j < mine && kr[j] >= T) S[atomicAdd(&s_cnt, 1u)] = kr[j];
+        for (int j = 0; j < FINAL_REG_KEYS; ++j) {
+          const int b = j < mine ? window_bin((uint32_t)(kr[j] >> 32)) : -1;   // (a struck-out candidate, key 0, is outside the window)
+          if (b >= 0) atomicAdd(&lh[b], 1u);
+        }
+        __syncthreads();
+        uint32_t bstar, k2;
+        pick_bucket<FINAL_THREADS>(lh, WBINS, (uint32_t)count, sh, &bstar, &k2);
+        bool done = false;
+        if (bstar != 0xffffffffu) {
+#pragma unroll
+          for (int j = 0; j < FINAL_REG_KEYS; ++j)
+            if (j < mine && window_bin((uint32_t)(kr[j] >> 32)) >= (int)bstar) {
+              const uint32_t slot = atomicAdd(&s_cnt, 1u);
+              if (slot < (uint32_t)SORT_CAP) S[slot] = kr[j];
+            }
+          __syncthreads();
+          const uint32_t total = s_cnt;
+          __syncthreads();
+          if (total <= (uint32_t)SORT_CAP) {
+            m = next_pow2((int)total < 2 ? 2 : (int)total);
+            for (int i = (int)total + threadIdx.x; i < m; i += blockDim.x) S[i] = 0ull;
+            done = true;
+          }
+        }
+        if (!done) {
+          if (threadIdx.x == 0) s_cnt = 0;
+          for (int i = threadIdx.x; i < m; i += blockDim.x) S[i] = 0ull;
+          __syncthreads();
+          const uint64_t T = block_radix_select_regs(kr, mine, (uint32_t)count, lh, sh);
+#pragma unroll
+          for (int j = 0; j < FINAL_REG_KEYS; ++j)
+            if (j < mine && kr[j] >= T) S[atomicAdd(&s_cnt, 1u)] = kr[j];
+        }
       } else if (flag == 0 && n_cand <= (uint32_t)CAND_CAP) {
+        for (int i = threadIdx.x; i < m; i += blockDim.x) S[i] = 0ull;
         auto key_at = [&](int64_t i) { return cq[i]; };
         const uint64_t T = block_radix_select(key_at, (int64_t)n_cand, (uint32_t)count, lh, sh);
         for (int64_t i = threadIdx.x; i < (int64_t)n_cand; i += blockDim.x) {
@@ -444,6 +490,7 @@ __global__ __launch_bounds__(FINAL_THREADS) void select_final_kernel(
           if (key >= T) S[atomicAdd(&s_cnt, 1u)] = key;
         }
       } else {  // exact fallback over the raw scores (one CU; rare)
+        for (int i = threadIdx.x; i < m; i += blockDim.x) S[i] = 0ull;
         auto key_at = [&](int64_t i) { return make_key(s[i], (uint32_t)i); };
         const uint64_t T = block_radix_select(key_at, n, (uint32_t)count, lh, sh);
         for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
@@ -464,20 +511,29 @@ __global__ __launch_bounds__(FINAL_THREADS) void select_final_kernel(
 }
 
 // ---- fused path, thresholds: thr[q] = exact k-th best score of scores[q][0 .. n) ----
-// One workgroup per query: MSB radix select on the 32-bit orderable keys (11 + 11 + 10 bits),
-// the score vector read from L2 three times (64 KB at the usual 16,384-row prefix).  Replaces
-// histogram + filter + final (three launches, a sorted list nobody reads) when only the
-// k-th value is wanted: 62 -> ~15 us for 1024 queries.
+// One workgroup per query.  Replaces histogram + filter + final (three launches, a sorted list nobody
+// reads) when only the k-th value is wanted.  Prefixes of up to 16,384 rows are read ONCE into registers
+// (64 score keys per thread); then
+//   1. one histogram pass over the window bins of path A (the top 16 key bits, 128 bins per octave,
+//      [2^-31, 2]; negative scores are outside and cost nothing) finds the bin b* of the k-th best;
+//   2. the keys inside b* (a handful) are listed in LDS and the one of rank k' is found by counting.
+// (Round 3 ran three 11/11/10-bit radix passes over all keys: the first pass's bins are the sign, the
+// exponent and two mantissa bits, so the 16,384 scores of a prefix fell into ~20 LDS words and the atomics
+// of a wave were served one lane after the other -- 50 % of the kernel's LDS cycles were conflict cycles.)
+// A window that holds fewer than k keys (negative k-th best) or a bin with more than PK_LIST keys falls
+// back to that radix select: always exact.
+constexpr int PK_LIST = 1024;
 __global__ __launch_bounds__(FINAL_THREADS) void prefix_kth_kernel(
     const float* __restrict__ scores, int64_t n, int64_t score_stride, int k, float* __restrict__ thr) {
-  __shared__ uint32_t lh[RS_BINS];
+  __shared__ uint32_t lh[WBINS];
   __shared__ uint32_t sh[256 + 2];
+  __shared__ uint32_t list[PK_LIST];
+  __shared__ uint32_t s_cnt;
   const float* s = scores + (int64_t)blockIdx.x * score_stride;
   uint32_t prefix = 0, pmask = 0, k_rem = (uint32_t)k;
   const int shifts[3] = {21, 10, 0};
   constexpr int PK_REGS = 64;   // score keys per thread held in registers: prefixes of up to 16,384 rows are read ONCE
   if (n <= (int64_t)FINAL_THREADS * PK_REGS && (score_stride & 3) == 0 && (((uintptr_t)scores) & 15) == 0) {
-    // (three passes over the score vector in L2 were what this kernel cost: 200 MB for 1024 queries)
     uint32_t kr[PK_REGS];
 #pragma unroll
     for (int j = 0; j < PK_REGS / 4; ++j) {
@@ -495,6 +551,42 @@ __global__ __launch_bounds__(FINAL_THREADS) void prefix_kth_kernel(
       kr[4 * j + 2] = i + 2 < n ? score_key(q4.z) : 0u;
       kr[4 * j + 3] = i + 3 < n ? score_key(q4.w) : 0u;
     }
+    for (int i = threadIdx.x; i < WBINS; i += blockDim.x) lh[i] = 0;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PK_REGS; ++j) {
+      const int b = window_bin(kr[j]);   // (key 0 is outside the window)
+      if (b >= 0) atomicAdd(&lh[b], 1u);
+    }
+    __syncthreads();
+    uint32_t bstar, k2;
+    pick_bucket<FINAL_THREADS>(lh, WBINS, (uint32_t)k, sh, &bstar, &k2);
+    if (bstar != 0xffffffffu) {
+#pragma unroll
+      for (int j = 0; j < PK_REGS; ++j)
+        if (window_bin(kr[j]) == (int)bstar) {
+          const uint32_t slot = atomicAdd(&s_cnt, 1u);
+          if (slot < (uint32_t)PK_LIST) list[slot] = kr[j];
+        }
+      __syncthreads();
+      const uint32_t cnt = s_cnt;
+      if (cnt <= (uint32_t)PK_LIST) {
+        // the key of rank k2 (1-based from the top) among the cnt keys of the bin; equal scores share a rank range
+        for (uint32_t t = threadIdx.x; t < cnt; t += blockDim.x) {
+          const uint32_t mine = list[t];
+          uint32_t gt = 0, ge = 0;
+          for (uint32_t u = 0; u < cnt; ++u) {
+            const uint32_t o = list[u];
+            gt += o > mine ? 1u : 0u;
+            ge += o >= mine ? 1u : 0u;
+          }
+          if (gt < k2 && k2 <= ge) thr[blockIdx.x] = key_score(mine);
+        }
+        return;
+      }
+      __syncthreads();
+    }
     for (int pass = 0; pass < 3; ++pass) {
       const int shift = shifts[pass];
       const uint32_t bins = pass == 2 ? 1024u : (uint32_t)RS_BINS;
@@ -504,11 +596,11 @@ __global__ __launch_bounds__(FINAL_THREADS) void prefix_kth_kernel(
       for (int j = 0; j < PK_REGS; ++j)
         if (kr[j] != 0u && (kr[j] & pmask) == prefix) atomicAdd(&lh[(kr[j] >> shift) & (bins - 1)], 1u);
       __syncthreads();
-      uint32_t b, k2;
-      pick_bucket<256>(lh, (int)bins, k_rem, sh, &b, &k2);
+      uint32_t b, k3;
+      pick_bucket<256>(lh, (int)bins, k_rem, sh, &b, &k3);
       prefix |= b << shift;
       pmask |= (bins - 1) << shift;
-      k_rem = k2;
+      k_rem = k3;
     }
     if (threadIdx.x == 0) thr[blockIdx.x] = key_score(prefix);
     return;

@@ -3,6 +3,7 @@
 // scratch, so searches are re-entrant), launch sequencing of the score stage
 // (gemv_f32.h) and the top-k stage (select.h).  gfx950 only.
 #include "../../include/svs_amd.h"
+#include "internal.h"
 
 #include <hip/hip_runtime.h>
 
@@ -13,6 +14,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <shared_mutex>
 #include <new>
@@ -53,6 +55,99 @@ int fail(int code, const char* fmt, ...) {
                   #expr, hipGetErrorString(e_), __FILE__, __LINE__);                        \
   } while (0)
 
+// ---- internal tunables (svs_internal_tune: tools and tests; not part of the ABI) --------------------
+std::atomic<int64_t> g_tune_prefix_div{64};   // fused path: rows of the threshold prefix = n / this (>= FUSE_PREFIX_MIN)
+std::atomic<int64_t> g_tune_upload{0};        // host batches of more than 1 MiB: 0 = pooled host copy, 1 = round 3's serial staging
+std::atomic<int64_t> g_tune_pool{3};          // helper threads of the host copy pool (0: the caller copies alone)
+
+// ---- host copy pool -----------------------------------------------------------------------------------
+// A 1024 x 1536 f32 query batch is 6.3 MB: one thread moves it into the pinned staging area in ~0.3 ms,
+// a tenth of the whole configs[2] call and all of it in front of the first kernel.  A few parked helper
+// threads (made once per process, woken per batch) copy the later pieces while the calling thread copies
+// and enqueues the first ones.  (Round 3 measured a helper thread CREATED per call: slower than no helper.)
+// Protocol: a job is claimed with a CAS (0 -> 1) by whoever gets to it first -- a helper, under the queue
+// lock, at the moment it pops it, or the owner, who walks its own jobs in order and copies what nobody has
+// taken -- and marked 2 when copied.  The owner never waits for a sleeping helper, and purges what is left
+// of its jobs from the queue before they go out of scope.
+struct CopyJob {
+  void* dst = nullptr;
+  const void* src = nullptr;
+  size_t bytes = 0;
+  std::atomic<int> state{0};
+};
+class CopyPool {
+ public:
+  static CopyPool& get() {
+    static CopyPool* p = new CopyPool();   // never destroyed: its threads may outlive static destructors
+    return *p;
+  }
+  void submit(CopyJob* jobs, int n) {
+    const int want = (int)std::min<int64_t>(std::max<int64_t>(g_tune_pool.load(), 0), 8);
+    if (want == 0 || n <= 1) return;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      while ((int)threads_ < want) {
+        std::thread([this] { worker(); }).detach();
+        ++threads_;
+      }
+      for (int i = 1; i < n; ++i) q_.push_back(&jobs[i]);   // (job 0 is the owner's own first piece)
+    }
+    cv_.notify_all();
+  }
+  // owner: job i is copied when this returns
+  static void finish(CopyJob* j) {
+    int exp = 0;
+    if (j->state.compare_exchange_strong(exp, 1)) {
+      memcpy(j->dst, j->src, j->bytes);
+      j->state.store(2, std::memory_order_release);
+      return;
+    }
+    int spins = 0;
+    while (j->state.load(std::memory_order_acquire) != 2)
+      if (++spins > 2000) std::this_thread::yield();
+  }
+  // owner: none of jobs[0, n) is referenced by the pool afterwards (all of them are in state 2 by now)
+  void purge(CopyJob* jobs, int n) {
+    std::lock_guard<std::mutex> lk(mu_);
+    for (auto it = q_.begin(); it != q_.end();)
+      it = (*it >= jobs && *it < jobs + n) ? q_.erase(it) : it + 1;
+  }
+
+ private:
+  void worker() {
+    std::unique_lock<std::mutex> lk(mu_);
+    for (;;) {
+      CopyJob* j = nullptr;
+      while (!q_.empty()) {
+        CopyJob* c = q_.front();
+        q_.pop_front();
+        int exp = 0;
+        if (c->state.compare_exchange_strong(exp, 1)) { j = c; break; }
+      }
+      if (!j) {
+        // stay awake for a moment: the next batch of a busy caller finds running helpers
+        lk.unlock();
+        bool more = false;
+        for (int i = 0; i < 4000 && !more; ++i) {
+          __builtin_ia32_pause();
+          if ((i & 63) == 63) { lk.lock(); more = !q_.empty(); lk.unlock(); }
+        }
+        lk.lock();
+        if (!more && q_.empty()) cv_.wait(lk);
+        continue;
+      }
+      lk.unlock();
+      memcpy(j->dst, j->src, j->bytes);
+      j->state.store(2, std::memory_order_release);
+      lk.lock();
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::deque<CopyJob*> q_;
+  unsigned threads_ = 0;
+};
+
 struct EvTriple {
   hipEvent_t e0, e1, e2;
   hipEvent_t d0 = nullptr, d1 = nullptr;   // around the dominant kernel of a fused search (else unset)
@@ -80,6 +175,7 @@ struct Ctx {
   // last used it; handing it to ANOTHER stream first drains the old one.
   hipStream_t last_stream = nullptr;
   bool async_pending = false;
+  CopyJob* jobs = nullptr;     int jobs_cap = 0;        // host copies of the current search_host call (CopyPool)
 };
 
 }  // namespace
@@ -172,6 +268,7 @@ void ctx_destroy(Ctx* c) {
   (void)hipHostFree(c->q_pin);
   (void)hipHostFree(c->out_s_pin);
   (void)hipHostFree(c->out_r_pin);
+  delete[] c->jobs;
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -359,8 +456,10 @@ void launch_generic_f16(const svs_index* idx, const _Float16* qh, float* scores,
 int stage_queries_f16(const svs_index* idx, Ctx* c, const float* q, int nq, int rows_alloc, hipStream_t st) {
   int rc = grow_dev(&c->qh, &c->qh_cap, (size_t)rows_alloc * idx->ld);
   if (rc != SVS_OK) return rc;
-  if (rows_alloc > nq) HIP_TRY(hipMemsetAsync(c->qh, 0, (size_t)rows_alloc * idx->ld * sizeof(_Float16), st));
-  hipLaunchKernelGGL(convert_queries_f16_kernel, dim3((unsigned)std::min<int64_t>(2048, ((int64_t)nq * idx->ld + 255) / 256)), dim3(256), 0, st, q, nq, idx->d, c->qh, idx->ld);
+  _Float16* dst = c->qh;
+  // (the kernel writes whole padded rows: only the rows behind the queries need zeroing)
+  if (rows_alloc > nq) HIP_TRY(hipMemsetAsync(dst + (size_t)nq * idx->ld, 0, (size_t)(rows_alloc - nq) * idx->ld * sizeof(_Float16), st));
+  hipLaunchKernelGGL(convert_queries_f16_kernel, dim3((unsigned)std::min<int64_t>(2048, ((int64_t)nq * idx->ld + 255) / 256)), dim3(256), 0, st, q, nq, idx->d, dst, idx->ld);
   return SVS_OK;
 }
 
@@ -368,15 +467,16 @@ int stage_queries_f16(const svs_index* idx, Ctx* c, const float* q, int nq, int 
 // scales c->q8s; want_f32 also fills c->q8f with the quantised values as f32
 int stage_queries_fp8(const svs_index* idx, Ctx* c, const float* q, int nq, int rows_alloc, bool want_f32, hipStream_t st) {
   int rc;
-  if ((rc = grow_dev(&c->q8, &c->q8_cap, (size_t)rows_alloc * idx->ld)) != SVS_OK) return rc;
-  if ((rc = grow_dev(&c->q8s, &c->q8s_cap, (size_t)rows_alloc)) != SVS_OK) return rc;
-  if (want_f32 && (rc = grow_dev(&c->q8f, &c->q8f_cap, (size_t)rows_alloc * idx->ld)) != SVS_OK) return rc;
+  const size_t o = 0;
+  if ((rc = grow_dev(&c->q8, &c->q8_cap, (o + rows_alloc) * idx->ld)) != SVS_OK) return rc;
+  if ((rc = grow_dev(&c->q8s, &c->q8s_cap, o + rows_alloc)) != SVS_OK) return rc;
+  if (want_f32 && (rc = grow_dev(&c->q8f, &c->q8f_cap, (o + rows_alloc) * idx->ld)) != SVS_OK) return rc;
   if (rows_alloc > nq) {
-    HIP_TRY(hipMemsetAsync(c->q8, 0, (size_t)rows_alloc * idx->ld, st));
-    HIP_TRY(hipMemsetAsync(c->q8s, 0, (size_t)rows_alloc * sizeof(float), st));
+    HIP_TRY(hipMemsetAsync(c->q8 + (o + nq) * idx->ld, 0, (size_t)(rows_alloc - nq) * idx->ld, st));
+    HIP_TRY(hipMemsetAsync(c->q8s + o + nq, 0, (size_t)(rows_alloc - nq) * sizeof(float), st));
   }
   hipLaunchKernelGGL(quantize_rows_fp8_kernel, dim3((nq + 3) / 4), dim3(256), 0, st, q, (int64_t)nq, idx->d, (int64_t)idx->d,
-                     c->q8, idx->ld, c->q8s, want_f32 ? c->q8f : (float*)nullptr);
+                     c->q8 + o * idx->ld, idx->ld, c->q8s + o, want_f32 ? c->q8f + o * idx->ld : (float*)nullptr);
   return SVS_OK;
 }
 
@@ -748,17 +848,19 @@ int launch_scores_tiled(const svs_index* idx, Ctx* c, const float* q_dev, int64_
 int run_select(svs_index* idx, Ctx* c, const float* scores, int64_t n_eff, int64_t sstride, int nq, int k,
                int count, float* out_s, int64_t* out_r, hipStream_t st, int64_t row_offset) {
   int rc;
+  uint32_t* hist = c->hist;
+  uint64_t* cand = c->cand;
   if (n_eff <= SORT_CAP) {
     hipLaunchKernelGGL(select_final_kernel, dim3(nq), dim3(FINAL_THREADS), 0, st, scores, n_eff, sstride, k, count, 1,
                        (uint32_t*)nullptr, (uint64_t*)nullptr, row_offset, out_s, out_r, (const uint32_t*)nullptr);
   } else if (count <= SEL_KMAX) {
     const int64_t per_block = (int64_t)FA_THREADS * SEL_VPT * 4;
     const unsigned blocks = (unsigned)((n_eff + per_block - 1) / per_block);
-    hipLaunchKernelGGL(select_window_hist_kernel, dim3(blocks, nq), dim3(FA_THREADS), 0, st, scores, n_eff, sstride, c->hist);
+    hipLaunchKernelGGL(select_window_hist_kernel, dim3(blocks, nq), dim3(FA_THREADS), 0, st, scores, n_eff, sstride, hist);
     hipLaunchKernelGGL(select_window_filter_kernel, dim3(blocks, nq), dim3(FA_THREADS), 0, st, scores, n_eff, sstride,
-                       (uint32_t)count, c->hist, c->cand);
+                       (uint32_t)count, hist, cand);
     hipLaunchKernelGGL(select_final_kernel, dim3(nq), dim3(FINAL_THREADS), 0, st, scores, n_eff, sstride, k, count, 0,
-                       c->hist, c->cand, row_offset, out_s, out_r, (const uint32_t*)nullptr);
+                       hist, cand, row_offset, out_s, out_r, (const uint32_t*)nullptr);
   } else {
     int64_t npad;
     next_pow2_i64(n_eff, &npad);
@@ -828,28 +930,50 @@ int launch_scores_any(svs_index* idx, Ctx* c, const float* q_dev, int64_t n_rows
 
 constexpr int64_t FUSE_PREFIX_MIN = 16384;
 inline int64_t fuse_prefix_rows(int64_t n) {
-  const int64_t p = std::max<int64_t>(FUSE_PREFIX_MIN, n / 64);
+  const int64_t p = std::max<int64_t>(FUSE_PREFIX_MIN, n / std::max<int64_t>(g_tune_prefix_div.load(), 1));
   return (p + 127) / 128 * 128;
 }
 
-int enqueue_search(svs_index* idx, Ctx* c, const float* q_dev, int nq, int k, int count,
-                   float* out_s, int64_t* out_r, hipStream_t st, bool allow_fused = false) {
+// One search, enqueued in three steps (the host API sizes scratch and starts the timing events BEFORE it stages
+// the queries, so that everything the device does for a call sits between the call's events):
+//   plan_search     decisions (materialised / fused, prefix size), scratch, the timing start event
+//   enqueue_prefix  fused only: the queries staged in the corpus dtype, their scores over the prefix rows, their
+//                   thresholds (exact k-th best of the prefix)
+//   enqueue_main    fused: the whole-corpus pass with the threshold epilogue + final select; otherwise the
+//                   materialised score stage + top-k stage
+// (Round 4 built and measured the prefix step PER QUERY TILE -- tile t's staging, prefix GEMM and thresholds enqueued
+//  behind its DMA while tile t + 1 was still being copied: configs[2] 3.26 ms per call against 3.04.  One query tile's
+//  prefix GEMM is 64 output tiles, a quarter of the CUs, and takes as long as the whole batch's 256; and every
+//  copy -> kernel -> copy alternation on the stream is a hand-over between the DMA engine and the compute queue.)
+struct SearchPlan {
+  int nq = 0, k = 0, count = 0;
+  bool path_a = false, fused = false, kth = false, timed = false;
+  int64_t n_mat = 0, sstride = 0;
+  EvTriple ev{};
+};
+
+int plan_search(svs_index* idx, Ctx* c, int nq, int k, int count, hipStream_t st, bool allow_fused, SearchPlan* p) {
   const int64_t n = idx->n;
   int rc;
   if ((rc = staging_wait(idx)) != SVS_OK) return rc;
-  const bool path_a = k > 0 && n > SORT_CAP && count <= SEL_KMAX;
+  p->nq = nq; p->k = k; p->count = count;
+  p->path_a = k > 0 && n > SORT_CAP && count <= SEL_KMAX;
   // Fused top-k epilogue (no score matrix) for the batched kernels; a query whose
   // candidate list overflows comes back marked and is re-run by the caller.  The prefix
   // pass costs ~60 us whatever the batch: measured break-even is 16 queries (f32: 13.2 k vs
   // 12.7 k queries/s at 16, 6.4 k vs 6.5 k at 8; f16 at 32: 49 k vs 41 k; fp8 at 32: 77 k vs 64 k).
   const bool batched = uses_q16(idx, nq) || (nq >= 2 && tiled_ok(idx));
-  const bool fused = allow_fused && path_a && batched && nq >= 16 &&
-                     n >= 8 * FUSE_PREFIX_MIN && (int64_t)n < ((int64_t)1 << 32) &&
-                     count <= 256 && idx->variant.load() != 6;
-  const int64_t n_mat = fused ? fuse_prefix_rows(n) : n;     // rows of the materialised score matrix
-  const int64_t sstride = (n_mat + 3) & ~(int64_t)3;         // float4-aligned score vectors
-  if ((rc = grow_dev(&c->scores, &c->scores_cap, (size_t)nq * (size_t)sstride)) != SVS_OK) return rc;
-  if (path_a && (size_t)nq > c->hist_cap) {
+  p->fused = allow_fused && p->path_a && batched && nq >= 16 &&
+             n >= 8 * FUSE_PREFIX_MIN && (int64_t)n < ((int64_t)1 << 32) &&
+             count <= 256 && idx->variant.load() != 6;
+  p->n_mat = p->fused ? fuse_prefix_rows(n) : n;       // rows of the materialised score matrix
+  p->sstride = (p->n_mat + 3) & ~(int64_t)3;           // float4-aligned score vectors
+  // thresholds: many queries over a short prefix -> one k-th-value kernel (47 vs 62 us at 1024 x 16,384);
+  // otherwise the ordinary three-launch top-k, whose kernels spread one query over many workgroups
+  // (16 queries: 20 vs 33 us; 256 x 156,250 rows: 119 vs 284 us).
+  p->kth = p->fused && nq >= 256 && p->n_mat <= 32768;
+  if ((rc = grow_dev(&c->scores, &c->scores_cap, (size_t)nq * (size_t)p->sstride)) != SVS_OK) return rc;
+  if (p->path_a && (size_t)nq > c->hist_cap) {
     if (c->hist) HIP_TRY(hipFree(c->hist));
     if (c->cand) HIP_TRY(hipFree(c->cand));
     c->hist = nullptr; c->cand = nullptr; c->hist_cap = 0;
@@ -860,60 +984,79 @@ int enqueue_search(svs_index* idx, Ctx* c, const float* q_dev, int nq, int k, in
     HIP_TRY(hipMemsetAsync(c->hist, 0, scr_bytes, st));
     c->hist_cap = nq;
   }
-
-  EvTriple ev{};
-  const int tevery = idx->timing.load();
-  const bool timed = tevery > 0 && (idx->timing_seq.fetch_add(1) % (uint32_t)tevery) == 0;
-  if (timed) {
-    HIP_TRY(hipEventCreate(&ev.e0));
-    HIP_TRY(hipEventCreate(&ev.e1));
-    HIP_TRY(hipEventCreate(&ev.e2));
-    HIP_TRY(hipEventRecord(ev.e0, st));
+  if (p->fused) {
+    if ((rc = grow_dev(&c->pref_s, &c->pref_s_cap, (size_t)nq * (p->kth ? 1 : count))) != SVS_OK) return rc;
+    if (!p->kth && (rc = grow_dev(&c->pref_r, &c->pref_r_cap, (size_t)nq * count)) != SVS_OK) return rc;
   }
-  if (fused) {
-    // 1. thresholds: exact k-th best of the first FUSE_PREFIX_ROWS rows, per query.  Many queries
-    // over a short prefix: one k-th-value kernel (47 vs 62 us at 1024 x 16,384); otherwise the
-    // ordinary three-launch top-k, whose kernels spread one query over many workgroups
-    // (16 queries: 20 vs 33 us; 256 x 156,250 rows: 119 vs 284 us).
-    const bool kth = nq >= 256 && n_mat <= 32768;
-    if ((rc = grow_dev(&c->pref_s, &c->pref_s_cap, (size_t)nq * (kth ? 1 : count))) != SVS_OK) return rc;
-    if (!kth && (rc = grow_dev(&c->pref_r, &c->pref_r_cap, (size_t)nq * count)) != SVS_OK) return rc;
-    if ((rc = launch_scores_any(idx, c, q_dev, n_mat, nq, c->scores, sstride, FuseLaunch{}, st)) != SVS_OK) return rc;
-    if (!idx->dead_list.empty())   // thresholds must come from LIVE rows: masked prefix rows -> -inf (rows past the prefix are skipped)
-      hipLaunchKernelGGL(mask_dead_rows_kernel, dim3(64), dim3(256), 0, st, c->scores, sstride, nq, idx->dead_dev,
-                         (int64_t)idx->dead_list.size(), n_mat);
-    if (kth)
-      hipLaunchKernelGGL(prefix_kth_kernel, dim3(nq), dim3(FINAL_THREADS), 0, st, (const float*)c->scores, n_mat, sstride, count, c->pref_s);
-    else if ((rc = run_select(idx, c, c->scores, n_mat, sstride, nq, count, count, c->pref_s, c->pref_r, st, idx->row_offset)) != SVS_OK)
-      return rc;
-    // 2. the whole corpus, keeping only scores >= threshold
-    FuseLaunch fl{c->hist, c->cand, kth ? c->pref_s : c->pref_s + (count - 1), kth ? 1 : count};
-    if (timed) {
+  const int tevery = idx->timing.load();
+  p->timed = tevery > 0 && (idx->timing_seq.fetch_add(1) % (uint32_t)tevery) == 0;
+  if (p->timed) {
+    HIP_TRY(hipEventCreate(&p->ev.e0));
+    HIP_TRY(hipEventCreate(&p->ev.e1));
+    HIP_TRY(hipEventCreate(&p->ev.e2));
+    HIP_TRY(hipEventRecord(p->ev.e0, st));
+  }
+  return SVS_OK;
+}
+
+int enqueue_prefix(svs_index* idx, Ctx* c, const SearchPlan& p, const float* q_dev, hipStream_t st) {
+  if (!p.fused) return SVS_OK;
+  int rc;
+  const int nq = p.nq, count = p.count;
+  if ((rc = launch_scores_any(idx, c, q_dev, p.n_mat, nq, c->scores, p.sstride, FuseLaunch{}, st)) != SVS_OK) return rc;
+  if (!idx->dead_list.empty())   // thresholds must come from LIVE rows: masked prefix rows -> -inf (rows past the prefix are skipped)
+    hipLaunchKernelGGL(mask_dead_rows_kernel, dim3(64), dim3(256), 0, st, c->scores, p.sstride, nq, idx->dead_dev,
+                       (int64_t)idx->dead_list.size(), p.n_mat);
+  if (p.kth)
+    hipLaunchKernelGGL(prefix_kth_kernel, dim3(nq), dim3(FINAL_THREADS), 0, st, (const float*)c->scores, p.n_mat, p.sstride, count, c->pref_s);
+  else if ((rc = run_select(idx, c, c->scores, p.n_mat, p.sstride, nq, count, count, c->pref_s, c->pref_r, st, idx->row_offset)) != SVS_OK)
+    return rc;
+  return SVS_OK;
+}
+
+int enqueue_main(svs_index* idx, Ctx* c, SearchPlan& p, const float* q_dev, float* out_s, int64_t* out_r, hipStream_t st) {
+  const int64_t n = idx->n;
+  const int nq = p.nq, k = p.k, count = p.count;
+  int rc;
+  EvTriple& ev = p.ev;
+  if (p.fused) {
+    // the whole corpus, keeping only scores >= threshold (the queries are staged: enqueue_prefix)
+    FuseLaunch fl{c->hist, c->cand, p.kth ? c->pref_s : c->pref_s + (count - 1), p.kth ? 1 : count};
+    if (p.timed) {
       HIP_TRY(hipEventCreate(&ev.d0));
       HIP_TRY(hipEventCreate(&ev.d1));
       HIP_TRY(hipEventRecord(ev.d0, st));
     }
     if ((rc = launch_scores_any(idx, c, q_dev, n, nq, nullptr, 0, fl, st, false)) != SVS_OK) return rc;
-    if (timed) HIP_TRY(hipEventRecord(ev.d1, st));
-    if (timed) HIP_TRY(hipEventRecord(ev.e1, st));
+    if (p.timed) HIP_TRY(hipEventRecord(ev.d1, st));
+    if (p.timed) HIP_TRY(hipEventRecord(ev.e1, st));
     hipLaunchKernelGGL(select_final_kernel, dim3(nq), dim3(FINAL_THREADS), 0, st, (const float*)nullptr, n, (int64_t)0, k, count, 3,
                        c->hist, c->cand, idx->row_offset, out_s, out_r,
                        (const uint32_t*)(idx->dead_list.empty() ? nullptr : idx->dead_bits_dev));
   } else {
-    if ((rc = launch_scores_any(idx, c, q_dev, n, nq, c->scores, sstride, FuseLaunch{}, st)) != SVS_OK) return rc;
+    if ((rc = launch_scores_any(idx, c, q_dev, n, nq, c->scores, p.sstride, FuseLaunch{}, st)) != SVS_OK) return rc;
     if (!idx->dead_list.empty())   // tombstoned rows can never be returned
-      hipLaunchKernelGGL(mask_dead_rows_kernel, dim3(64), dim3(256), 0, st, c->scores, sstride, nq, idx->dead_dev,
+      hipLaunchKernelGGL(mask_dead_rows_kernel, dim3(64), dim3(256), 0, st, c->scores, p.sstride, nq, idx->dead_dev,
                          (int64_t)idx->dead_list.size(), n);
-    if (timed) HIP_TRY(hipEventRecord(ev.e1, st));
-    if (k > 0 && (rc = run_select(idx, c, c->scores, n, sstride, nq, k, count, out_s, out_r, st, idx->row_offset)) != SVS_OK) return rc;
+    if (p.timed) HIP_TRY(hipEventRecord(ev.e1, st));
+    if (k > 0 && (rc = run_select(idx, c, c->scores, n, p.sstride, nq, k, count, out_s, out_r, st, idx->row_offset)) != SVS_OK) return rc;
   }
   HIP_TRY(hipGetLastError());
-  if (timed) {
+  if (p.timed) {
     HIP_TRY(hipEventRecord(ev.e2, st));
     std::lock_guard<std::mutex> lk(idx->mu);
     idx->evs.push_back(ev);
   }
   return SVS_OK;
+}
+
+int enqueue_search(svs_index* idx, Ctx* c, const float* q_dev, int nq, int k, int count,
+                   float* out_s, int64_t* out_r, hipStream_t st, bool allow_fused = false) {
+  SearchPlan p;
+  int rc;
+  if ((rc = plan_search(idx, c, nq, k, count, st, allow_fused, &p)) != SVS_OK) return rc;
+  if ((rc = enqueue_prefix(idx, c, p, q_dev, st)) != SVS_OK) return rc;
+  return enqueue_main(idx, c, p, q_dev, out_s, out_r, st);
 }
 
 // Holds one reference for the duration of a call.  Declared BEFORE the geometry lock in every
@@ -1585,20 +1728,66 @@ static int32_t search_host(svs_index* idx, const float* queries, int32_t nq, int
     HIP_TRY(hipHostMalloc((void**)&c->out_r_pin, on * sizeof(int64_t), hipHostMallocDefault));
     c->out_pin_cap = on;
   }
-  // queries -> pinned staging -> HBM, in 1 MiB pieces: the DMA of piece i runs under the host copy of
-  // piece i + 1 (a 1024 x 1536 batch is 6.3 MB: ~0.3 ms of memcpy + ~0.13 ms of PCIe back to back).
-  // (Measured and dropped in round 3: a helper thread copying the odd pieces while this one copies the even ones --
-  //  the call got 0.35 ms SLOWER, 3.49 vs 3.07-3.12 ms at 1024 x 1536: creating and joining the thread costs more
-  //  than half a host copy saves.)
-  for (size_t off = 0; off < qn; off += (size_t)262144) {
-    const size_t len = std::min((size_t)262144, qn - off);
-    memcpy(c->q_pin + off, queries + off, len * sizeof(float));
-    HIP_TRY(hipMemcpyAsync(c->q_dev + off, c->q_pin + off, len * sizeof(float), hipMemcpyHostToDevice, c->stream));
-  }
   // The final top-k kernel stores its k results straight into the pinned host
   // buffers (device-visible, zero-copy): no D2H copies on the latency path.
-  if ((rc = enqueue_search(idx, c, c->q_dev, nq, count, count, c->out_s_pin, c->out_r_pin, c->stream, true)) != SVS_OK) {
+  SearchPlan plan;
+  if ((rc = plan_search(idx, c, nq, count, count, c->stream, true, &plan)) != SVS_OK) return rc;
+  const size_t qbytes = qn * sizeof(float);
+  if (qbytes < ((size_t)1 << 20) || g_tune_upload.load() == 1) {
+    // queries -> pinned staging -> HBM, in 1 MiB pieces: the DMA of piece i runs under the host copy of
+    // piece i + 1 (round 3's path; still the one for everything up to 1 MiB: a single query is 6 KB)
+    for (size_t off = 0; off < qn; off += (size_t)262144) {
+      const size_t len = std::min((size_t)262144, qn - off);
+      memcpy(c->q_pin + off, queries + off, len * sizeof(float));
+      HIP_TRY(hipMemcpyAsync(c->q_dev + off, c->q_pin + off, len * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    }
+  } else {
+    // Large batches (a 1024 x 1536 batch is 6.3 MB): the host copy is cut into chunks of whole queries, copied by the
+    // caller and the parked helper threads of CopyPool at once; each chunk's DMA is enqueued, in order, as soon as the
+    // chunk is in pinned memory.
+    int cq = 256;                                           // queries per chunk: <= 1 MiB, a power of two
+    while (cq > 1 && (size_t)cq * d * sizeof(float) > ((size_t)1 << 20)) cq >>= 1;
+    const int nj = (nq + cq - 1) / cq;
+    if (nj > c->jobs_cap) {
+      delete[] c->jobs;
+      c->jobs = nullptr; c->jobs_cap = 0;
+      c->jobs = new (std::nothrow) CopyJob[(size_t)std::max(nj, 8)];
+      if (!c->jobs) return fail(SVS_ERR_NOMEM, "host allocation failed");
+      c->jobs_cap = std::max(nj, 8);
+    }
+    for (int j = 0; j < nj; ++j) {
+      const size_t off = (size_t)j * cq * d, len = std::min((size_t)cq * d, qn - off);
+      c->jobs[j].dst = c->q_pin + off;
+      c->jobs[j].src = queries + off;
+      c->jobs[j].bytes = len * sizeof(float);
+      c->jobs[j].state.store(0, std::memory_order_relaxed);
+    }
+    CopyPool& pool = CopyPool::get();
+    pool.submit(c->jobs, nj);
+    hipError_t he = hipSuccess;
+    for (int j = 0; j < nj; ++j) {
+      CopyPool::finish(&c->jobs[j]);                        // (copies it itself if no helper has taken it)
+      if (he != hipSuccess) continue;                       // (still retire every job: the pool must not see them again)
+      const size_t off = (size_t)j * cq * d;
+      he = hipMemcpyAsync(c->q_dev + off, c->q_pin + off, c->jobs[j].bytes, hipMemcpyHostToDevice, c->stream);
+    }
+    pool.purge(c->jobs, nj);
+    if (he != hipSuccess) rc = fail(SVS_ERR_DEVICE, "query upload: %s", hipGetErrorString(he));
+  }
+  if (rc == SVS_OK) rc = enqueue_prefix(idx, c, plan, c->q_dev, c->stream);
+  if (rc == SVS_OK) rc = enqueue_main(idx, c, plan, c->q_dev, c->out_s_pin, c->out_r_pin, c->stream);
+  if (rc != SVS_OK) {
     (void)hipStreamSynchronize(c->stream);
+    if (plan.timed && plan.ev.e0) {   // (a failed search keeps no events)
+      std::lock_guard<std::mutex> lk(idx->mu);
+      bool kept = false;
+      for (auto& t : idx->evs) kept = kept || t.e0 == plan.ev.e0;
+      if (!kept) {
+        (void)hipEventDestroy(plan.ev.e0); (void)hipEventDestroy(plan.ev.e1); (void)hipEventDestroy(plan.ev.e2);
+        if (plan.ev.d0) (void)hipEventDestroy(plan.ev.d0);
+        if (plan.ev.d1) (void)hipEventDestroy(plan.ev.d1);
+      }
+    }
     return rc;
   }
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1613,6 +1802,20 @@ static int32_t search_host(svs_index* idx, const float* queries, int32_t nq, int
     HIP_TRY(hipStreamSynchronize(c->stream));
   }
   // device layout has stride `count`; the caller's has stride k
+  if (count == k && on * 12 >= ((size_t)1 << 20) && c->jobs_cap >= 4 && g_tune_upload.load() != 1) {
+    // (a 1024 x 100 result is 1.2 MB: the same pool moves it out, the rows in halves)
+    const size_t h = on / 2;
+    CopyJob* jb = c->jobs;
+    jb[0].dst = out_rows;       jb[0].src = c->out_r_pin;     jb[0].bytes = h * sizeof(int64_t);
+    jb[1].dst = out_rows + h;   jb[1].src = c->out_r_pin + h; jb[1].bytes = (on - h) * sizeof(int64_t);
+    jb[2].dst = out_scores;     jb[2].src = c->out_s_pin;     jb[2].bytes = on * sizeof(float);
+    for (int j = 0; j < 3; ++j) jb[j].state.store(0, std::memory_order_relaxed);
+    CopyPool& pool = CopyPool::get();
+    pool.submit(jb, 3);
+    for (int j = 0; j < 3; ++j) CopyPool::finish(&jb[j]);
+    pool.purge(jb, 3);
+    return SVS_OK;
+  }
   for (int qi = 0; qi < nq; ++qi) {
     memcpy(out_scores + (size_t)qi * k, c->out_s_pin + (size_t)qi * count, (size_t)count * sizeof(float));
     memcpy(out_rows + (size_t)qi * k, c->out_r_pin + (size_t)qi * count, (size_t)count * sizeof(int64_t));
@@ -1688,7 +1891,7 @@ int32_t svs_index_search(svs_index* idx, const float* queries, int32_t nq, int32
         if (idx->co_hold > 0) {   // (tests / benchmarks: a pass of a chosen size; bounded, so a miscounted test cannot hang)
           const int want = idx->co_hold;
           idx->co_hold_cv.wait_for(lk, std::chrono::seconds(5), [&] { return (int)idx->co_pending.size() >= want; });
-          idx->co_hold = 0;
+          if (idx->co_hold == want) idx->co_hold = 0;   // (one shot; a hold set by another thread meanwhile stays)
         }
         // f32: whole kernel tiles -- the exact-f32 MFMA kernels cost the same for 33 queries as for 64 (1.8 vs 1.2 ms
         // for 32), so a queue that does not fill the next tile size leaves its tail for the following pass.
@@ -1731,9 +1934,11 @@ int32_t svs_index_coalesce_stats(svs_index* idx, int64_t* passes, int64_t* queri
   return SVS_OK;
 }
 
-int32_t svs_index_coalesce_hold(svs_index* idx, int32_t n) {
+// (tests and tools only -- csrc/internal.h, not in include/svs_amd.h: the NEXT coalesced pass waits, at most 5 s,
+//  until n single-query calls are queued, so that a pass of a chosen size can be formed on purpose)
+int32_t svs_internal_coalesce_hold(svs_index* idx, int32_t n) {
   if (!idx) return fail(SVS_ERR_INVALID, "null index");
-  if (n < 0 || n > 256) return fail(SVS_ERR_INVALID, "svs_index_coalesce_hold: 0 <= n <= 256");
+  if (n < 0 || n > 256) return fail(SVS_ERR_INVALID, "svs_internal_coalesce_hold: 0 <= n <= 256");
   std::lock_guard<std::mutex> lk(idx->co_mu);
   idx->co_hold = n;
   return SVS_OK;
@@ -1772,13 +1977,18 @@ int32_t svs_index_search_device(svs_index* idx, const float* dev_queries, int32_
   return rc;
 }
 
-int32_t svs_index_scores(svs_index* idx, const float* query, int32_t d, float* out_scores) {
+int32_t svs_index_scores_n(svs_index* idx, const float* query, int32_t d, float* out_scores, int64_t out_capacity,
+                           int64_t* out_n) {
   if (!idx) return fail(SVS_ERR_INVALID, "null index");
   RefGuard guard(idx);
-  std::shared_lock<std::shared_mutex> geo(idx->rw);
+  std::shared_lock<std::shared_mutex> geo(idx->rw);   // (appends / commits take it exclusively: idx->n cannot move below)
+  if (out_n) *out_n = idx->n;
   int rc = check_query_args(idx, query, 1, d);
   if (rc != SVS_OK) return rc;
   if (!out_scores) return fail(SVS_ERR_INVALID, "null output");
+  if (out_capacity < idx->n)
+    return fail(SVS_ERR_INVALID, "svs_index_scores_n: the index holds %lld rows, the output buffer %lld floats "
+                                 "(rows were appended since it was sized?)", (long long)idx->n, (long long)out_capacity);
   HIP_TRY(hipSetDevice(idx->device));
   if ((rc = staging_wait(idx)) != SVS_OK) return rc;
   Ctx* c = nullptr;
@@ -1905,6 +2115,16 @@ int32_t svs_index_get_timing(svs_index* idx, svs_timing_t* out) {
     if (t.d1) (void)hipEventDestroy(t.d1);
   }
   return rc;
+}
+
+int32_t svs_internal_tune(int32_t what, int64_t value) {
+  switch (what) {
+    case 0: if (value < 1) break; g_tune_prefix_div.store(value); return SVS_OK;
+    case 1: if (value < 0 || value > 1) break; g_tune_upload.store(value); return SVS_OK;
+    case 2: if (value < 0 || value > 8) break; g_tune_pool.store(value); return SVS_OK;
+    default: break;
+  }
+  return fail(SVS_ERR_INVALID, "svs_internal_tune(%d, %lld): unknown knob or value", what, (long long)value);
 }
 
 int32_t svs_index_set_variant(svs_index* idx, int32_t variant) {

@@ -226,15 +226,26 @@ class DeviceIndex:
         q = np.ascontiguousarray(query_vec, dtype=np.float32)
         if q.ndim != 1:
             raise ValueError(f"query must be 1-D, got shape {q.shape}")
-        self._refresh()      # svs_index_scores writes one f32 per row the HANDLE holds now (appends / commits since)
-        out = np.empty(self.n, dtype=np.float32)
         h = self._pinned_handle()
         try:
-            _native.check(self._lib.svs_index_scores(
-                h, q.ctypes.data_as(C.c_void_p), q.shape[0], out.ctypes.data_as(C.c_void_p)))
+            # The library writes one f32 per row the HANDLE holds when the call runs, never more than the capacity
+            # passed: if rows were appended (another thread, another owner of the handle) since the buffer was
+            # sized, the call fails, reports the new count, and is repeated with a buffer of that size.
+            rows = self.n
+            for _ in range(8):
+                out = np.empty(rows, dtype=np.float32)
+                now = C.c_int64(0)
+                rc = self._lib.svs_index_scores_n(h, q.ctypes.data_as(C.c_void_p), q.shape[0],
+                                                  out.ctypes.data_as(C.c_void_p), rows, C.byref(now))
+                if rc == _native.SVS_OK:
+                    return out[:now.value]
+                if now.value <= rows:
+                    break
+                rows = now.value
+            _native.check(rc)
+            raise RuntimeError("svs_index_scores_n: the index kept growing")
         finally:
             self._lib.svs_index_release(h)
-        return out
 
     def search_device(self, q_ptr: int, nq: int, d: int, k: int, out_scores_ptr: int,
                       out_rows_ptr: int, stream: int = 0) -> int:
@@ -309,8 +320,8 @@ class DeviceIndex:
         return p.value, q.value
 
     def coalesce_hold(self, n: int) -> None:
-        """The next coalesced pass waits (at most 5 s) for n queued callers (svs_index_coalesce_hold; tests)."""
-        _native.check(self._lib.svs_index_coalesce_hold(self._handle(), int(n)))
+        """The next coalesced pass waits (at most 5 s) for n queued callers (svs_internal_coalesce_hold; tests)."""
+        _native.check(self._lib.svs_internal_coalesce_hold(self._handle(), int(n)))
 
     def coalesce_sizes(self) -> dict:
         """{queries per pass: passes} of the coalescing path (svs_index_coalesce_sizes)."""

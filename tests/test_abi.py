@@ -152,3 +152,35 @@ def test_c_caller_masks_rows_while_multi_searches_run(gpu, tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.startswith("ok"), (out.returncode, out.stdout, out.stderr)
     print(out.stdout.strip())
+
+
+def test_c_scores_race_program_builds(tmp_path):
+    """CPU: tests/c/scores_race.c compiles and links against the ABI."""
+    import shutil
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    assert os.path.exists(_build_c(tmp_path, "scores_race"))
+
+
+@pytest.mark.gpu
+def test_c_caller_reads_scores_while_rows_are_appended(gpu, tmp_path):
+    """svs_index_scores_n sized from svs_index_info() while another thread appends (tests/c/scores_race.c): a full
+    vector or SVS_ERR_INVALID with the row count to retry with, never a write past the capacity (VERDICT r3 item 5:
+    round 3's capacity-less entry overflowed the caller's heap here)."""
+    import subprocess
+    exe = _build_c(tmp_path, "scores_race")
+    out = subprocess.run([str(exe), "3"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.startswith("ok"), (out.returncode, out.stdout, out.stderr)
+    print(out.stdout.strip())
+
+
+def test_internal_hooks_are_exported_but_not_in_the_public_header():
+    """svs_internal_* (svs_amd/csrc/internal.h: test / tool hooks) are exported by the library and stay out of
+    include/svs_amd.h (svs_index_coalesce_hold was a public entry that could stall every queued search)."""
+    lib = _native.load()
+    public = _declared_symbols()
+    for s in _native.INTERNAL:
+        assert hasattr(lib, s), s
+        assert s not in public, s
+    assert not hasattr(lib, "svs_index_coalesce_hold")
+    assert not hasattr(lib, "svs_index_scores"), "the capacity-less entry must be gone (its binding must fail at load time)"

@@ -60,3 +60,42 @@ def test_pipelined_exchange_with_real_ranks(gpu, tmp_path, world, n, d, nq, k, g
         assert [int(x) for x in got["rows"][i]] == [r for _, r in exp], f"query {i}: rows differ from one index"
         assert [float(x) for x in got["scores"][i]] == [s for s, _ in exp], f"query {i}: score bits differ from one index"
     whole.release()
+
+
+ROOT = os.path.dirname(HERE)
+
+
+def _bench_line(args, env_extra, timeout=900):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    for k_ in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k_, None)                       # no launcher: bench.py must start its own ranks
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
+    import json
+    return json.loads(lines[0])
+
+
+def test_bench_launches_its_own_ranks(gpu):
+    """`python bench.py --gpus 2` with NO launcher and no RANK in the environment (the shape of the driver's N = 1
+    command): bench.py starts two rank processes of itself, they rendezvous on 127.0.0.1 (gloo here: the two ranks
+    share the box's one card), rank 0's JSON line comes back alone, and with SVS_BENCH_VERIFY=1 the merged results of
+    the timed steps equal one index over the whole corpus, rows and score bits."""
+    line = _bench_line(["--gpus", "2", "--steps", "20", "--warmup", "5", "--rows", "200000"],
+                       {"SVS_BENCH_BACKEND": "gloo", "SVS_BENCH_VERIFY": "1"})
+    assert line["n_gpus"] == 2 and line["steps"] == 20 and line["scaling"] == "strong"
+    assert line["sharded_check"] == {"queries": 16, "mismatches": 0}
+    assert line["config"]["rows_per_gpu"] == 100000 and line["value"] > 0
+
+
+def test_bench_config3_weak_and_multi_modes(gpu):
+    """`--config 3` (BASELINE.json configs[3]: f16 rows per GPU, weak scaling; here with a reduced --rows so that two
+    ranks and the whole-corpus check fit the time budget) through self-launched ranks, and `--multi`: the same shards
+    in one process through svs_multi_search."""
+    line = _bench_line(["--gpus", "2", "--config", "3", "--rows", "150000", "--steps", "10", "--warmup", "3"],
+                       {"SVS_BENCH_BACKEND": "gloo", "SVS_BENCH_VERIFY": "1"})
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["dtype"] == "f16"
+    assert line["config"]["rows_per_gpu"] == 150000 and line["sharded_check"]["mismatches"] == 0
+    multi = _bench_line(["--gpus", "2", "--multi", "--rows", "200000", "--steps", "10", "--warmup", "3"], {})
+    assert multi["n_gpus"] == 2 and "svs_multi" in multi["config"]["path"] and multi["config"]["rows_per_shard"] == [100000, 100000]
+    assert multi["value"] > 0

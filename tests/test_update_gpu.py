@@ -202,3 +202,28 @@ def test_build_from_device_blocks(gpu, dtype):
     with pytest.raises(ValueError):
         idx.append_device(wide.data_ptr(), 10, src_ld=d - 1)
     idx.release(); ref.release()
+
+
+def test_scores_after_append_through_another_owner(gpu):
+    """`scores()` on a wrapper whose row count is stale (the rows were appended through another owner of the same
+    handle): svs_index_scores_n refuses the short buffer, reports the handle's row count, and the wrapper repeats the
+    call with it -- round 3's capacity-less entry wrote past the buffer here (gpurun_out/r3c_tests.log)."""
+    from svs_amd import DeviceIndex
+    m, qs = corpus_and_query("gaussian", 321, 9000, 200, 1)
+    idx = DeviceIndex(m[:5000])
+    other = idx.share()
+    other.append(m[5000:])
+    assert idx.n == 5000 and other.n == 9000          # this wrapper has not looked since
+    got = idx.scores(qs[0])
+    assert got.shape == (9000,)
+    np.testing.assert_allclose(got, oracle.cpu_scores(m, qs[0]), atol=1e-5, rtol=0)
+    # the C entry itself: a short capacity is an error that names the row count, nothing is written
+    import ctypes as C
+    from svs_amd import _native
+    lib = _native.load()
+    buf = np.full(5000 + 16, 7.0, dtype=np.float32)
+    now = C.c_int64(0)
+    rc = lib.svs_index_scores_n(idx._handle(), qs[0].ctypes.data_as(C.c_void_p), 200, buf.ctypes.data_as(C.c_void_p), 5000, C.byref(now))
+    assert rc == _native.SVS_ERR_INVALID and now.value == 9000 and (buf == 7.0).all()
+    other.release()
+    idx.release()

@@ -8,6 +8,10 @@ tag=${1:-r1}
 part=${2:-ab}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out
+# identity of the kernel sources these passes measure (content hash of svs_amd/csrc + the header: svs_amd/buildinfo.py):
+# written on the GPU box at profile time (it has no .git), read by the summarisers, checked by bench.py before it
+# quotes any traffic figure from profiles/
+python3 $R/svs_amd/buildinfo.py > $O/prof_${tag}_csrc_sha.txt
 cd /tmp && export TMPDIR=/tmp
 run() { local name=$1; shift; rm -rf "$O/prof_${tag}_$name"; rocprofv3 "$@"; echo "[profile_round] $name done" >&2; }
 if [[ $part == *a* ]]; then

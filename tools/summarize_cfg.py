@@ -29,6 +29,11 @@ def newest(pat):
 
 
 short = lambda k: k.split("(")[0]
+def csrc_stamp():
+    """csrc_sha16 the passes were stamped with ON THE GPU BOX at profile time (tools/profile_round.sh); a profile without the
+    stamp is marked so -- bench.py then refuses to quote its traffic."""
+    f = os.path.join(src, f"prof_{tag}_csrc_sha.txt")
+    return open(f).read().strip() if os.path.exists(f) else "unstamped"
 def git_head():
     """The commit the profiled tree was at (the GPU box has no .git: summarise right after the run, before the next commit)."""
     import subprocess
@@ -39,7 +44,7 @@ def git_head():
     except Exception:
         return os.environ.get("SVS_GIT_HEAD", "unrecorded")
 
-out = {"tag": tag, "git_head": git_head(), "config": name, "command": cmd, "kernels": {}, "pmc": {}}
+out = {"tag": tag, "git_head": git_head(), "csrc_sha16": csrc_stamp(), "config": name, "command": cmd, "kernels": {}, "pmc": {}}
 stats = newest(os.path.join(src, f"prof_{tag}_{name}_trace", "*", "*_kernel_stats.csv"))
 if stats:
     shutil.copy(stats, os.path.join(dst, f"{tag}_{name}_kernel_stats.csv"))

@@ -41,6 +41,11 @@ for k, v in pmc.items():
     v["hbm_read_bytes_per_launch"] = rd
     v["hbm_write_bytes_per_launch"] = wr
     v["hbm_bytes_per_launch"] = rd + wr
+def csrc_stamp():
+    """csrc_sha16 the passes were stamped with ON THE GPU BOX at profile time (tools/profile_round.sh); a profile without the
+    stamp is marked so -- bench.py then refuses to quote its traffic."""
+    f = os.path.join(src, f"prof_{tag}_csrc_sha.txt")
+    return open(f).read().strip() if os.path.exists(f) else "unstamped"
 def git_head():
     """The commit the profiled tree was at (the GPU box has no .git: summarise right after the run, before the next commit)."""
     import subprocess
@@ -50,7 +55,7 @@ def git_head():
         return h + ("+uncommitted" if dirty else "")
     except Exception:
         return os.environ.get("SVS_GIT_HEAD", "unrecorded")
-out = {"tag": tag, "git_head": git_head(), "kernels": kern, "pmc": pmc,
+out = {"tag": tag, "git_head": git_head(), "csrc_sha16": csrc_stamp(), "kernels": kern, "pmc": pmc,
        "note": "FETCH_SIZE x2 (gfx950 reports half of a wide coalesced read), KiB units; WRITE_SIZE exact"}
 json.dump(out, open(os.path.join(dst, f"{tag}_summary.json"), "w"), indent=1)
 bench = os.path.join(src, f"prof_{tag}_trace.json")
