@@ -92,6 +92,7 @@ SIGNATURES = {
 INTERNAL = {
     "svs_internal_coalesce_hold": (C.c_int32, [_P, C.c_int32]),
     "svs_internal_tune": (C.c_int32, [C.c_int32, C.c_int64]),
+    "svs_internal_host_phases": (C.c_int32, [C.POINTER(C.c_double), C.c_int32]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -13,9 +13,13 @@ extern "C" {
 int32_t svs_internal_coalesce_hold(svs_index* idx, int32_t n);
 /* Process-wide knobs for A/B measurements:
  *   0  fused path: threshold prefix = n / value rows (default 64; at least 16,384 rows)
- *   1  host batches of more than 1 MiB: 0 = host copies through the helper-thread pool (default), 1 = serial staging (round 3)
- *   2  helper threads of the host copy pool (default 3; 0 = none) */
+ *   1  host batches: 0 = f16 / fp8 batches pulled from pinned memory by the staging kernels, chunk by chunk (default);
+ *      1 = staged DMA for every dtype (round 3) */
 int32_t svs_internal_tune(int32_t what, int64_t value);
+/* Seconds since the start of the calling thread's last svs_index_search(host batch) at which: [0] scratch was planned,
+ * [1] the queries were in pinned memory (and their DMA enqueued), [2] every kernel was enqueued, [3] the stream had
+ * drained, [4] the results were in the caller's buffers. */
+int32_t svs_internal_host_phases(double* out, int32_t n);
 /* multi.hip -> svs_amd.hip: carries a worker thread's error message over to the caller's thread */
 int32_t svs_internal_set_error(int32_t code, const char* msg);
 #ifdef __cplusplus

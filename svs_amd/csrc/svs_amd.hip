@@ -14,7 +14,6 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
-#include <deque>
 #include <mutex>
 #include <shared_mutex>
 #include <new>
@@ -57,96 +56,9 @@ int fail(int code, const char* fmt, ...) {
 
 // ---- internal tunables (svs_internal_tune: tools and tests; not part of the ABI) --------------------
 std::atomic<int64_t> g_tune_prefix_div{64};   // fused path: rows of the threshold prefix = n / this (>= FUSE_PREFIX_MIN)
-std::atomic<int64_t> g_tune_upload{0};        // host batches of more than 1 MiB: 0 = pooled host copy, 1 = round 3's serial staging
-std::atomic<int64_t> g_tune_pool{3};          // helper threads of the host copy pool (0: the caller copies alone)
-
-// ---- host copy pool -----------------------------------------------------------------------------------
-// A 1024 x 1536 f32 query batch is 6.3 MB: one thread moves it into the pinned staging area in ~0.3 ms,
-// a tenth of the whole configs[2] call and all of it in front of the first kernel.  A few parked helper
-// threads (made once per process, woken per batch) copy the later pieces while the calling thread copies
-// and enqueues the first ones.  (Round 3 measured a helper thread CREATED per call: slower than no helper.)
-// Protocol: a job is claimed with a CAS (0 -> 1) by whoever gets to it first -- a helper, under the queue
-// lock, at the moment it pops it, or the owner, who walks its own jobs in order and copies what nobody has
-// taken -- and marked 2 when copied.  The owner never waits for a sleeping helper, and purges what is left
-// of its jobs from the queue before they go out of scope.
-struct CopyJob {
-  void* dst = nullptr;
-  const void* src = nullptr;
-  size_t bytes = 0;
-  std::atomic<int> state{0};
-};
-class CopyPool {
- public:
-  static CopyPool& get() {
-    static CopyPool* p = new CopyPool();   // never destroyed: its threads may outlive static destructors
-    return *p;
-  }
-  void submit(CopyJob* jobs, int n) {
-    const int want = (int)std::min<int64_t>(std::max<int64_t>(g_tune_pool.load(), 0), 8);
-    if (want == 0 || n <= 1) return;
-    {
-      std::lock_guard<std::mutex> lk(mu_);
-      while ((int)threads_ < want) {
-        std::thread([this] { worker(); }).detach();
-        ++threads_;
-      }
-      for (int i = 1; i < n; ++i) q_.push_back(&jobs[i]);   // (job 0 is the owner's own first piece)
-    }
-    cv_.notify_all();
-  }
-  // owner: job i is copied when this returns
-  static void finish(CopyJob* j) {
-    int exp = 0;
-    if (j->state.compare_exchange_strong(exp, 1)) {
-      memcpy(j->dst, j->src, j->bytes);
-      j->state.store(2, std::memory_order_release);
-      return;
-    }
-    int spins = 0;
-    while (j->state.load(std::memory_order_acquire) != 2)
-      if (++spins > 2000) std::this_thread::yield();
-  }
-  // owner: none of jobs[0, n) is referenced by the pool afterwards (all of them are in state 2 by now)
-  void purge(CopyJob* jobs, int n) {
-    std::lock_guard<std::mutex> lk(mu_);
-    for (auto it = q_.begin(); it != q_.end();)
-      it = (*it >= jobs && *it < jobs + n) ? q_.erase(it) : it + 1;
-  }
-
- private:
-  void worker() {
-    std::unique_lock<std::mutex> lk(mu_);
-    for (;;) {
-      CopyJob* j = nullptr;
-      while (!q_.empty()) {
-        CopyJob* c = q_.front();
-        q_.pop_front();
-        int exp = 0;
-        if (c->state.compare_exchange_strong(exp, 1)) { j = c; break; }
-      }
-      if (!j) {
-        // stay awake for a moment: the next batch of a busy caller finds running helpers
-        lk.unlock();
-        bool more = false;
-        for (int i = 0; i < 4000 && !more; ++i) {
-          __builtin_ia32_pause();
-          if ((i & 63) == 63) { lk.lock(); more = !q_.empty(); lk.unlock(); }
-        }
-        lk.lock();
-        if (!more && q_.empty()) cv_.wait(lk);
-        continue;
-      }
-      lk.unlock();
-      memcpy(j->dst, j->src, j->bytes);
-      j->state.store(2, std::memory_order_release);
-      lk.lock();
-    }
-  }
-  std::mutex mu_;
-  std::condition_variable cv_;
-  std::deque<CopyJob*> q_;
-  unsigned threads_ = 0;
-};
+std::atomic<int64_t> g_tune_upload{0};        // host batches: 0 = f16 / fp8 batches are PULLED from pinned memory by the staging kernels, chunk by chunk
+                                              // (no DMA, no f32 copy in HBM); 1 = round 3's staging + DMA for every dtype
+thread_local double g_host_phase[6];          // svs_internal_host_phases: seconds since the call began (last svs_index_search on this thread)
 
 struct EvTriple {
   hipEvent_t e0, e1, e2;
@@ -175,7 +87,6 @@ struct Ctx {
   // last used it; handing it to ANOTHER stream first drains the old one.
   hipStream_t last_stream = nullptr;
   bool async_pending = false;
-  CopyJob* jobs = nullptr;     int jobs_cap = 0;        // host copies of the current search_host call (CopyPool)
 };
 
 }  // namespace
@@ -268,7 +179,6 @@ void ctx_destroy(Ctx* c) {
   (void)hipHostFree(c->q_pin);
   (void)hipHostFree(c->out_s_pin);
   (void)hipHostFree(c->out_r_pin);
-  delete[] c->jobs;
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -453,10 +363,13 @@ void launch_generic_f16(const svs_index* idx, const _Float16* qh, float* scores,
 }
 
 // rounds nq f32 queries to half into c->qh ([rows_alloc][ld], rows >= nq zero)
-int stage_queries_f16(const svs_index* idx, Ctx* c, const float* q, int nq, int rows_alloc, hipStream_t st) {
+// (row0 > 0: a later chunk of a batch staged piece by piece -- search_host; the buffer was grown by the first chunk's
+//  call, which passes the whole batch's row count as rows_alloc, and only the last chunk zeroes the padding rows)
+int stage_queries_f16(const svs_index* idx, Ctx* c, const float* q, int nq, int rows_alloc, hipStream_t st, int row0 = 0) {
   int rc = grow_dev(&c->qh, &c->qh_cap, (size_t)rows_alloc * idx->ld);
   if (rc != SVS_OK) return rc;
-  _Float16* dst = c->qh;
+  _Float16* dst = c->qh + (size_t)row0 * idx->ld;
+  rows_alloc -= row0;
   // (the kernel writes whole padded rows: only the rows behind the queries need zeroing)
   if (rows_alloc > nq) HIP_TRY(hipMemsetAsync(dst + (size_t)nq * idx->ld, 0, (size_t)(rows_alloc - nq) * idx->ld * sizeof(_Float16), st));
   hipLaunchKernelGGL(convert_queries_f16_kernel, dim3((unsigned)std::min<int64_t>(2048, ((int64_t)nq * idx->ld + 255) / 256)), dim3(256), 0, st, q, nq, idx->d, dst, idx->ld);
@@ -465,12 +378,13 @@ int stage_queries_f16(const svs_index* idx, Ctx* c, const float* q, int nq, int 
 
 // quantises nq f32 queries to e4m3 into c->q8 ([rows_alloc][ld] bytes, rows >= nq zero) with
 // scales c->q8s; want_f32 also fills c->q8f with the quantised values as f32
-int stage_queries_fp8(const svs_index* idx, Ctx* c, const float* q, int nq, int rows_alloc, bool want_f32, hipStream_t st) {
+int stage_queries_fp8(const svs_index* idx, Ctx* c, const float* q, int nq, int rows_alloc, bool want_f32, hipStream_t st, int row0 = 0) {
   int rc;
-  const size_t o = 0;
-  if ((rc = grow_dev(&c->q8, &c->q8_cap, (o + rows_alloc) * idx->ld)) != SVS_OK) return rc;
-  if ((rc = grow_dev(&c->q8s, &c->q8s_cap, o + rows_alloc)) != SVS_OK) return rc;
-  if (want_f32 && (rc = grow_dev(&c->q8f, &c->q8f_cap, (o + rows_alloc) * idx->ld)) != SVS_OK) return rc;
+  const size_t o = (size_t)row0;
+  if ((rc = grow_dev(&c->q8, &c->q8_cap, (size_t)rows_alloc * idx->ld)) != SVS_OK) return rc;
+  if ((rc = grow_dev(&c->q8s, &c->q8s_cap, (size_t)rows_alloc)) != SVS_OK) return rc;
+  if (want_f32 && (rc = grow_dev(&c->q8f, &c->q8f_cap, (size_t)rows_alloc * idx->ld)) != SVS_OK) return rc;
+  rows_alloc -= row0;
   if (rows_alloc > nq) {
     HIP_TRY(hipMemsetAsync(c->q8 + (o + nq) * idx->ld, 0, (size_t)(rows_alloc - nq) * idx->ld, st));
     HIP_TRY(hipMemsetAsync(c->q8s + o + nq, 0, (size_t)(rows_alloc - nq) * sizeof(float), st));
@@ -892,6 +806,14 @@ bool uses_q16(const svs_index* idx, int nq) {
   return nq <= GQ || idx->variant.load() == 5 || !tiled_ok(idx);
 }
 
+// Rows of the staged (half / e4m3) query image the batched kernels read for nq queries: the batch padded to the
+// query tile of the kernel that will take it (launch_scores_any / launch_scores_tiled use the same rule).
+int staged_rows(const svs_index* idx, int nq) {
+  if (uses_q16(idx, nq)) return (nq + GQ - 1) / GQ * GQ;
+  const int bn = nq <= 32 ? 32 : (nq <= 64 ? 64 : (nq <= 128 ? 128 : 256));
+  return (nq + bn - 1) / bn * bn;
+}
+
 // rows [0, n_rows); fl.state != null: fused epilogue (batched kernels only); restage == false
 // reuses the queries staged by the previous call on this context.
 int launch_scores_any(svs_index* idx, Ctx* c, const float* q_dev, int64_t n_rows, int nq, float* scores, int64_t sstride,
@@ -948,6 +870,7 @@ inline int64_t fuse_prefix_rows(int64_t n) {
 struct SearchPlan {
   int nq = 0, k = 0, count = 0;
   bool path_a = false, fused = false, kth = false, timed = false;
+  bool staged = false;   // the caller has staged the queries in the corpus dtype already (search_host, chunk by chunk)
   int64_t n_mat = 0, sstride = 0;
   EvTriple ev{};
 };
@@ -1003,7 +926,7 @@ int enqueue_prefix(svs_index* idx, Ctx* c, const SearchPlan& p, const float* q_d
   if (!p.fused) return SVS_OK;
   int rc;
   const int nq = p.nq, count = p.count;
-  if ((rc = launch_scores_any(idx, c, q_dev, p.n_mat, nq, c->scores, p.sstride, FuseLaunch{}, st)) != SVS_OK) return rc;
+  if ((rc = launch_scores_any(idx, c, q_dev, p.n_mat, nq, c->scores, p.sstride, FuseLaunch{}, st, !p.staged)) != SVS_OK) return rc;
   if (!idx->dead_list.empty())   // thresholds must come from LIVE rows: masked prefix rows -> -inf (rows past the prefix are skipped)
     hipLaunchKernelGGL(mask_dead_rows_kernel, dim3(64), dim3(256), 0, st, c->scores, p.sstride, nq, idx->dead_dev,
                        (int64_t)idx->dead_list.size(), p.n_mat);
@@ -1034,7 +957,7 @@ int enqueue_main(svs_index* idx, Ctx* c, SearchPlan& p, const float* q_dev, floa
                        c->hist, c->cand, idx->row_offset, out_s, out_r,
                        (const uint32_t*)(idx->dead_list.empty() ? nullptr : idx->dead_bits_dev));
   } else {
-    if ((rc = launch_scores_any(idx, c, q_dev, n, nq, c->scores, p.sstride, FuseLaunch{}, st)) != SVS_OK) return rc;
+    if ((rc = launch_scores_any(idx, c, q_dev, n, nq, c->scores, p.sstride, FuseLaunch{}, st, !p.staged)) != SVS_OK) return rc;
     if (!idx->dead_list.empty())   // tombstoned rows can never be returned
       hipLaunchKernelGGL(mask_dead_rows_kernel, dim3(64), dim3(256), 0, st, c->scores, p.sstride, nq, idx->dead_dev,
                          (int64_t)idx->dead_list.size(), n);
@@ -1730,52 +1653,54 @@ static int32_t search_host(svs_index* idx, const float* queries, int32_t nq, int
   }
   // The final top-k kernel stores its k results straight into the pinned host
   // buffers (device-visible, zero-copy): no D2H copies on the latency path.
+  const auto t_begin = std::chrono::steady_clock::now();
+  auto stamp = [&](int i) { g_host_phase[i] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
   SearchPlan plan;
   if ((rc = plan_search(idx, c, nq, count, count, c->stream, true, &plan)) != SVS_OK) return rc;
-  const size_t qbytes = qn * sizeof(float);
-  if (qbytes < ((size_t)1 << 20) || g_tune_upload.load() == 1) {
-    // queries -> pinned staging -> HBM, in 1 MiB pieces: the DMA of piece i runs under the host copy of
-    // piece i + 1 (round 3's path; still the one for everything up to 1 MiB: a single query is 6 KB)
+  stamp(0);
+  const int64_t mode = g_tune_upload.load();
+  // f16 / fp8 batches: the staging kernel (convert_queries_f16 / quantize_rows_fp8) reads the f32 queries STRAIGHT out of
+  // the pinned buffer, over PCIe, once (fp8: twice), and writes the half / e4m3 image the GEMM kernels use -- no copy-engine
+  // transfer, no f32 copy of the queries in HBM, no hand-over between the DMA engine and the compute queue in front of the
+  // first kernel -- and it does so CHUNK BY CHUNK (<= 1 MiB of whole queries): chunk j is pulled over the bus while the host
+  // copies chunk j + 1 into pinned memory.  Measured on configs[2] (6.3 MB of queries; tools/call_breakdown.py): the host copy
+  // takes 0.15 ms, the bus 0.13 ms whichever engine drives it; one after the other (round 3) they cost 0.28 ms in front of
+  // the first GEMM, overlapped ~0.16.  f32 indexes keep the staged DMA: their kernels read the f32 queries themselves, many
+  // times.  (Also measured and dropped: helper threads sharing the host copy -- the pool's hand-offs cost what it saved,
+  // 0.112 vs 0.088 ms to fill the pinned buffer; and the prefix pass per query tile, see SearchPlan.)
+  const bool pull = mode == 0 && idx->dtype != SVS_DTYPE_F32 && (uses_q16(idx, nq) || (nq >= 2 && tiled_ok(idx)));
+  const float* q_src = pull ? c->q_pin : c->q_dev;
+  if (pull) {
+    const int rows_total = staged_rows(idx, nq);
+    int cq = 256;                                           // queries per chunk: <= 1 MiB, a power of two
+    while (cq > 1 && (size_t)cq * d * sizeof(float) > ((size_t)1 << 20)) cq >>= 1;
+    for (int q0 = 0; q0 < nq && rc == SVS_OK; q0 += cq) {
+      const int nc = std::min(cq, nq - q0);
+      const size_t off = (size_t)q0 * d;
+      memcpy(c->q_pin + off, queries + off, (size_t)nc * d * sizeof(float));
+      // (rows_total on every call: the first sizes the image for the whole batch, the last zeroes its padding rows)
+      const int upto = q0 + nc == nq ? rows_total : q0 + nc;
+      if (q0 == 0 && upto < rows_total)   // size the image once, for the whole batch
+        rc = idx->dtype == SVS_DTYPE_F16 ? grow_dev(&c->qh, &c->qh_cap, (size_t)rows_total * idx->ld)
+                                         : ((rc = grow_dev(&c->q8, &c->q8_cap, (size_t)rows_total * idx->ld)) != SVS_OK ? rc
+                                                : grow_dev(&c->q8s, &c->q8s_cap, (size_t)rows_total));
+      if (rc == SVS_OK)
+        rc = idx->dtype == SVS_DTYPE_F16 ? stage_queries_f16(idx, c, c->q_pin + off, nc, upto, c->stream, q0)
+                                         : stage_queries_fp8(idx, c, c->q_pin + off, nc, upto, false, c->stream, q0);
+    }
+    plan.staged = true;
+  } else {
+    // queries -> pinned staging -> HBM, in 1 MiB pieces: the DMA of piece i runs under the host copy of piece i + 1
     for (size_t off = 0; off < qn; off += (size_t)262144) {
       const size_t len = std::min((size_t)262144, qn - off);
       memcpy(c->q_pin + off, queries + off, len * sizeof(float));
       HIP_TRY(hipMemcpyAsync(c->q_dev + off, c->q_pin + off, len * sizeof(float), hipMemcpyHostToDevice, c->stream));
     }
-  } else {
-    // Large batches (a 1024 x 1536 batch is 6.3 MB): the host copy is cut into chunks of whole queries, copied by the
-    // caller and the parked helper threads of CopyPool at once; each chunk's DMA is enqueued, in order, as soon as the
-    // chunk is in pinned memory.
-    int cq = 256;                                           // queries per chunk: <= 1 MiB, a power of two
-    while (cq > 1 && (size_t)cq * d * sizeof(float) > ((size_t)1 << 20)) cq >>= 1;
-    const int nj = (nq + cq - 1) / cq;
-    if (nj > c->jobs_cap) {
-      delete[] c->jobs;
-      c->jobs = nullptr; c->jobs_cap = 0;
-      c->jobs = new (std::nothrow) CopyJob[(size_t)std::max(nj, 8)];
-      if (!c->jobs) return fail(SVS_ERR_NOMEM, "host allocation failed");
-      c->jobs_cap = std::max(nj, 8);
-    }
-    for (int j = 0; j < nj; ++j) {
-      const size_t off = (size_t)j * cq * d, len = std::min((size_t)cq * d, qn - off);
-      c->jobs[j].dst = c->q_pin + off;
-      c->jobs[j].src = queries + off;
-      c->jobs[j].bytes = len * sizeof(float);
-      c->jobs[j].state.store(0, std::memory_order_relaxed);
-    }
-    CopyPool& pool = CopyPool::get();
-    pool.submit(c->jobs, nj);
-    hipError_t he = hipSuccess;
-    for (int j = 0; j < nj; ++j) {
-      CopyPool::finish(&c->jobs[j]);                        // (copies it itself if no helper has taken it)
-      if (he != hipSuccess) continue;                       // (still retire every job: the pool must not see them again)
-      const size_t off = (size_t)j * cq * d;
-      he = hipMemcpyAsync(c->q_dev + off, c->q_pin + off, c->jobs[j].bytes, hipMemcpyHostToDevice, c->stream);
-    }
-    pool.purge(c->jobs, nj);
-    if (he != hipSuccess) rc = fail(SVS_ERR_DEVICE, "query upload: %s", hipGetErrorString(he));
   }
-  if (rc == SVS_OK) rc = enqueue_prefix(idx, c, plan, c->q_dev, c->stream);
-  if (rc == SVS_OK) rc = enqueue_main(idx, c, plan, c->q_dev, c->out_s_pin, c->out_r_pin, c->stream);
+  stamp(1);
+  if (rc == SVS_OK) rc = enqueue_prefix(idx, c, plan, q_src, c->stream);
+  if (rc == SVS_OK) rc = enqueue_main(idx, c, plan, q_src, c->out_s_pin, c->out_r_pin, c->stream);
+  stamp(2);
   if (rc != SVS_OK) {
     (void)hipStreamSynchronize(c->stream);
     if (plan.timed && plan.ev.e0) {   // (a failed search keeps no events)
@@ -1791,9 +1716,12 @@ static int32_t search_host(svs_index* idx, const float* queries, int32_t nq, int
     return rc;
   }
   HIP_TRY(hipStreamSynchronize(c->stream));
+  stamp(3);
   // queries whose fused candidate list overflowed (marked row -2): exact re-run, one by one
   for (int qi = 0; qi < nq; ++qi) {
     if (c->out_r_pin[(size_t)qi * count] != -2) continue;
+    // (a pulled batch has no copy in HBM: the single-query kernels read their query many times, so it goes there first)
+    if (pull) HIP_TRY(hipMemcpyAsync(c->q_dev + (size_t)qi * d, c->q_pin + (size_t)qi * d, (size_t)d * sizeof(float), hipMemcpyHostToDevice, c->stream));
     if ((rc = enqueue_search(idx, c, c->q_dev + (size_t)qi * d, 1, count, count, c->out_s_pin + (size_t)qi * count,
                              c->out_r_pin + (size_t)qi * count, c->stream, false)) != SVS_OK) {
       (void)hipStreamSynchronize(c->stream);
@@ -1802,24 +1730,17 @@ static int32_t search_host(svs_index* idx, const float* queries, int32_t nq, int
     HIP_TRY(hipStreamSynchronize(c->stream));
   }
   // device layout has stride `count`; the caller's has stride k
-  if (count == k && on * 12 >= ((size_t)1 << 20) && c->jobs_cap >= 4 && g_tune_upload.load() != 1) {
-    // (a 1024 x 100 result is 1.2 MB: the same pool moves it out, the rows in halves)
-    const size_t h = on / 2;
-    CopyJob* jb = c->jobs;
-    jb[0].dst = out_rows;       jb[0].src = c->out_r_pin;     jb[0].bytes = h * sizeof(int64_t);
-    jb[1].dst = out_rows + h;   jb[1].src = c->out_r_pin + h; jb[1].bytes = (on - h) * sizeof(int64_t);
-    jb[2].dst = out_scores;     jb[2].src = c->out_s_pin;     jb[2].bytes = on * sizeof(float);
-    for (int j = 0; j < 3; ++j) jb[j].state.store(0, std::memory_order_relaxed);
-    CopyPool& pool = CopyPool::get();
-    pool.submit(jb, 3);
-    for (int j = 0; j < 3; ++j) CopyPool::finish(&jb[j]);
-    pool.purge(jb, 3);
+  if (count == k) {   // (one piece each)
+    memcpy(out_scores, c->out_s_pin, on * sizeof(float));
+    memcpy(out_rows, c->out_r_pin, on * sizeof(int64_t));
+    stamp(4);
     return SVS_OK;
   }
   for (int qi = 0; qi < nq; ++qi) {
     memcpy(out_scores + (size_t)qi * k, c->out_s_pin + (size_t)qi * count, (size_t)count * sizeof(float));
     memcpy(out_rows + (size_t)qi * k, c->out_r_pin + (size_t)qi * count, (size_t)count * sizeof(int64_t));
   }
+  stamp(4);
   return SVS_OK;
 }
 
@@ -2121,10 +2042,14 @@ int32_t svs_internal_tune(int32_t what, int64_t value) {
   switch (what) {
     case 0: if (value < 1) break; g_tune_prefix_div.store(value); return SVS_OK;
     case 1: if (value < 0 || value > 1) break; g_tune_upload.store(value); return SVS_OK;
-    case 2: if (value < 0 || value > 8) break; g_tune_pool.store(value); return SVS_OK;
     default: break;
   }
   return fail(SVS_ERR_INVALID, "svs_internal_tune(%d, %lld): unknown knob or value", what, (long long)value);
+}
+
+int32_t svs_internal_host_phases(double* out, int32_t n) {
+  for (int i = 0; i < n && i < 5; ++i) out[i] = g_host_phase[i];
+  return SVS_OK;
 }
 
 int32_t svs_index_set_variant(svs_index* idx, int32_t variant) {

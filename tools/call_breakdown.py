@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where the time of a host-API batch call goes, under the library's internal knobs (svs_internal_tune):
-upload = serial staging (round 3) or host copies through the helper-thread pool, the number of helper threads,
+upload = staged DMA (round 3) or the staging kernels pulling chunk by chunk from pinned memory,
 the threshold prefix (n / div rows); and the throughput of TWO callers in flight on one handle.
 usage: call_breakdown.py N D dtype nq [reps=12] [prefix divisors=64,128]"""
 import sys, os, time, threading
@@ -43,21 +43,25 @@ def one(label):
     score_ms, select_ms, cnt = idx.get_timing()
     dom = idx.last_dominant_ms_sum / max(cnt, 1)
     idx.set_timing(False)
-    print("%-44s call %.3f ms (min %.3f)  dominant kernel %.3f  score stage %.3f  select %.3f  -> outside the kernel %.3f ms"
-          % (label, float(np.median(ts)), min(ts), dom, score_ms / cnt, select_ms / cnt, float(np.median(ts)) - dom), flush=True)
+    import ctypes as C
+    ph = (C.c_double * 5)()
+    lib.svs_internal_host_phases(ph, 5)
+    print("%-40s call %.3f ms (min %.3f)  dominant kernel %.3f  score stage %.3f  select %.3f  -> outside the kernel %.3f ms | last call, host side (ms since entry): "
+          "planned %.3f, queries in pinned memory %.3f, all enqueued %.3f, stream drained %.3f, results copied out %.3f"
+          % (label, float(np.median(ts)), min(ts), dom, score_ms / cnt, select_ms / cnt, float(np.median(ts)) - dom, *[x * 1e3 for x in ph]), flush=True)
     return out
 
 
 ref = None
 for rd in range(2):
-    for upload, pool, div in [(1, 0, 64), (0, 0, 64), (0, 1, 64), (0, 3, 64)] + [(0, 3, dv) for dv in divs if dv != 64]:
-        tune(1, upload); tune(2, pool); tune(0, div)
-        out = one("round %d upload=%s pool=%d prefix=n/%d" % (rd, "serial" if upload else "pooled", pool, div))
+    for upload, div in [(1, 64), (0, 64)] + [(0, dv) for dv in divs if dv != 64]:
+        tune(1, upload); tune(0, div)
+        out = one("round %d upload=%s prefix=n/%d" % (rd, {0: "chunked pull", 1: "staged dma (r3)"}[upload], div))
         if ref is None:
             ref = out
         else:
             assert (out[1] == ref[1]).all() and (out[0] == ref[0]).all(), "results differ between knob settings"
-tune(1, 0); tune(2, 3); tune(0, 64)
+tune(1, 0); tune(0, 64)
 
 # two callers in flight (each its own thread, its own query batch; ctypes releases the GIL inside the call)
 for callers in (1, 2, 3):
