@@ -510,6 +510,10 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
 #define PG_C(v) std::integral_constant<int, (v)>{}
   constexpr bool kStage = EXP != 1 && EXP != 26, kRead = EXP != 2 && EXP != 5 && EXP != 25 && EXP != 26 && EXP != 45 && EXP != 46, kMma = EXP != 3 && EXP != 5 && EXP != 25 && EXP != 26 && EXP != 45 && EXP != 46;   // (45: tile-major corpus, DMA + barriers only)   // (26: barriers only)   // (EXP 5: LDS-DMA and barriers only)
   constexpr bool kDmaInMma = (PG_DMA_IN_MMA != 0) != (EXP == 30);   // (EXP 30: the other placement, A/B)
+  // (the between-the-MFMAs placement issues BOTH pieces of a half-tile unconditionally; at 128-query tiles a query half-tile is
+  //  one piece per wave -- stage() skips the second there -- so that placement, and with it variants 8 / 9 of
+  //  svs_index_set_variant, exists at 256-query tiles only: the 128-query route always takes EXP 20 / 0)
+  static_assert(!(kDmaInMma && QT == 128), "LDS-DMA pieces between the MFMAs: 256-query tiles only");
   // what follows the loads of a phase: [retire the B reads] wait for the NEXT phase's data, barrier,
   // fragments in, 16 MFMAs at raised priority (keeps hipcc from moving them over the barriers), barrier
 #define PG_SYNC_AND_MMA(PH, I, J, FB, LGKM8, LAND, KIND, SLOT, NEXT, KT_)    \

@@ -103,16 +103,31 @@ __device__ __forceinline__ void tg_epilogue(f32x4_t (&acc)[MT][NT], int64_t row0
                                             const float* __restrict__ fthr, int fthr_stride,
                                             const float* __restrict__ rscale, const float* __restrict__ qscale,
                                             const TgPairs pairs = TgPairs{}) {
+  // (an opaque copy of the lane id: formed from the kernel's own `lane`, the per-lane offsets and codes of this epilogue are
+  //  computed BEFORE the k loop and held across it -- at the 256 x 256 fp8 tile that is what does not fit 256 registers)
+  asm volatile("" : "+v"(lane));
   const int r16 = lane & 15, g = lane >> 4;
-  // fp8: the lane's MT * 4 row scales, fetched once (they are the same for every query tile)
-  f32x4_t rs[EB == 1 ? MT : 1];
+  // fp8 dequantisation, v * (row scale * query scale), one 16-row block at a time: its four row scales and the NT query
+  // scales are all that is live beside the accumulators.  (Fetched up front for all MT blocks -- 32 registers at the 256 x 256
+  // tile -- the scales pushed gemm_tiled_kernel<256, true, 1, 256> to 96 spilled registers and 52 bytes of scratch.)
   if constexpr (EB == 1) {
+    float qsc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int query = q0 + wq + j * 16 + r16;
+      qsc[j] = query < nq ? qscale[query] : 0.f;   // (a padded query's accumulators are never read)
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
+      f32x4_t rs;
       const int64_t ob = row0 + wrow + i * 16 + 4 * g;
-      if (ob + 3 < n) rs[i] = *(const f32x4_t*)(rscale + ob);   // row tiles start on multiples of 4
+      if (ob + 3 < n) rs = *(const f32x4_t*)(rscale + ob);   // row tiles start on multiples of 4
       else
-        for (int r = 0; r < 4; ++r) rs[i][r] = rscale[ob + r < n ? ob + r : n - 1];
+        for (int r = 0; r < 4; ++r) rs[r] = rscale[ob + r < n ? ob + r : n - 1];
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] *= rs[r] * qsc[j];
     }
   }
   // D layout: column (query) = lane & 15, rows 4 g + r of each 16-row tile
@@ -120,13 +135,6 @@ __device__ __forceinline__ void tg_epilogue(f32x4_t (&acc)[MT][NT], int64_t row0
   for (int j = 0; j < NT; ++j) {
     const int query = q0 + wq + j * 16 + r16;
     if (query < nq) {
-      if constexpr (EB == 1) {   // per-row and per-query dequantisation scales
-        const float qs = qscale[query];
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[i][j][r] *= rs[i][r] * qs;
-      }
       if constexpr (FUSE) {
         // A lane holds MT * 4 scores of ONE query here.  It counts its survivors first and
         // claims all their slots with ONE atomic (a returning atomic per surviving score made

@@ -96,3 +96,33 @@ def test_no_ring_drain_between_tile_loop_header_and_k_loop(build_reports):
         assert len(mfma) >= 32, f"{pretty}: {len(mfma)} MFMAs in what should be the k loop (two k-tiles: 32 at fp8 128-query tiles .. 128 at f16 256-query tiles)"
         checked += 1
     assert checked >= 10
+
+
+def test_no_shipped_gemm_kernel_touches_scratch_inside_its_k_loop(build_reports):
+    """Every GEMM kernel the library dispatches to (gemm_phased / gemm_tiled / gemm_q16r, all instantiations): no VGPR spill
+    and no scratch access -- with ONE documented exception, gemm_tiled_kernel<256, true, 1, 256> (the fp8 256 x 256 tile with
+    the fused epilogue: the fallback for rows with an odd number of 128-byte k-tiles, d = 384, 640, 1152 ...), whose 128
+    accumulators + epilogue temporaries do not fit 256 registers: its spills must all sit in the EPILOGUE, after the k loop,
+    where nothing is in flight that a scratch reload's vmcnt(0) could drain (the scratch gate only
+    looked at gemm_phased_kernel)."""
+    table = _resources(build_reports[0])
+    gemm = [n for n in table if any(k in n for k in ("gemm_phased_kernel", "gemm_tiled_kernel", "gemm_q16r_kernel", "gemm_f32_q16_kernel"))]
+    names = _demangle(gemm)
+    assert len(names) >= 40, len(names)
+    with open(build_reports[1]) as f:
+        isa = f.read().splitlines()
+    allowed = "gemm_tiled_kernel<256, true, 1, 256>"
+    seen_allowed = False
+    for mangled, pretty in names.items():
+        r = table[mangled]
+        if allowed in pretty:
+            seen_allowed = True
+            body = _function_body(isa, mangled)
+            mfma = [i for i, l in enumerate(body) if "v_mfma" in l]
+            scr = [i for i, l in enumerate(body) if "scratch_" in l]
+            assert len(mfma) >= 32 and scr, (len(mfma), len(scr))
+            # the k loop is the only place with MFMAs; the epilogue follows it in the layout
+            assert min(scr) > max(mfma), f"{pretty}: scratch access at line {min(scr)} of the kernel, before its last MFMA ({max(mfma)})"
+            continue
+        assert r["scratch"] == 0 and r["vgpr_spill"] == 0, f"{pretty}: {r}"
+    assert seen_allowed
