@@ -118,6 +118,30 @@ __device__ __forceinline__ void pick_bucket(const uint32_t* hist, int bins, uint
   __syncthreads();
 }
 
+// k-th largest of ONE 32-bit value per thread of a 256-thread workgroup (k <= 256; values of 0 mean "none").  The values go
+// through the LDS once; wave 0 then holds four of them per lane and bisects the key space bit by bit -- 32 rounds of four
+// compares, four ballots and scalar counting: no atomics, no further barrier.  Returns 0 when fewer than k values are non-zero.
+// Every thread of the workgroup must call this; `sh` is 256 + 1 words of LDS.
+__device__ __forceinline__ uint32_t block_kth_of_thread_values(uint32_t v, uint32_t k, uint32_t* sh) {
+  sh[threadIdx.x] = v;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const uint32_t a = sh[threadIdx.x], b = sh[threadIdx.x + 64], c = sh[threadIdx.x + 128], d = sh[threadIdx.x + 192];
+    uint32_t T = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+      const uint32_t cand = T | (1u << bit);
+      const uint32_t cnt = (uint32_t)(__builtin_popcountll(__ballot(a >= cand)) + __builtin_popcountll(__ballot(b >= cand)) +
+                                      __builtin_popcountll(__ballot(c >= cand)) + __builtin_popcountll(__ballot(d >= cand)));
+      if (cnt >= k) T = cand;   // (wave-uniform)
+    }
+    if (threadIdx.x == 0) sh[256] = T;
+  }
+  __syncthreads();
+  const uint32_t T = sh[256];
+  __syncthreads();
+  return T;
+}
+
 // Each thread of the histogram / filter kernels owns SEL_VPT float4 groups of
 // the score vector, all requested before the first is used (the vector is
 // L2/MALL resident, so the pass is latency-, not bandwidth-bound).
@@ -419,7 +443,7 @@ __global__ __launch_bounds__(FINAL_THREADS) void select_final_kernel(
     if (mode == 3 && (n_cand > (uint32_t)CAND_CAP || n_live < (uint32_t)count)) {
       __syncthreads();
       uint32_t* w0 = scratch + (int64_t)qi * SCR_WORDS;
-      for (int i = threadIdx.x; i < SCR_WORDS; i += blockDim.x) w0[i] = 0;
+      for (int i = threadIdx.x; i < (int)(sizeof(SelHeader) / 4); i += blockDim.x) w0[i] = 0;   // (mode 3 only: see below)
       for (int i = threadIdx.x; i < k_out; i += blockDim.x) {
         os[i] = -__builtin_inff();
         orow[i] = -2;
@@ -445,6 +469,50 @@ __global__ __launch_bounds__(FINAL_THREADS) void select_final_kernel(
         const int mine = (int)n_cand > (int)threadIdx.x ? ((int)n_cand - (int)threadIdx.x + FINAL_THREADS - 1) / FINAL_THREADS : 0;
 #pragma unroll
         for (int j = 0; j < FINAL_REG_KEYS; ++j) kr[j] = j < mine ? cq[threadIdx.x + j * FINAL_THREADS] : 0ull;
+        bool done = false;
+        __syncthreads();   // s_cnt = 0 is visible
+        if (count <= FINAL_THREADS) {
+          // (count <= 256) As in prefix_kth_kernel: the count-th largest of the per-thread maxima of the SCORE half of the keys
+          // bounds the count-th best score from below; the few hundred keys at or above it are listed by ballot + prefix count
+          // (one LDS atomic per wave) and sorted.  No histogram, no scattered LDS atomics.
+          uint32_t tmax = 0;
+#pragma unroll
+          for (int j = 0; j < FINAL_REG_KEYS; ++j) {
+            const uint32_t sk = (uint32_t)(kr[j] >> 32);
+            tmax = sk > tmax ? sk : tmax;
+          }
+          const uint32_t L = block_kth_of_thread_values(tmax, (uint32_t)count, sh);
+          if (L != 0u) {
+            const int lane = (int)(threadIdx.x & 63);
+            uint32_t cw = 0;
+#pragma unroll
+            for (int j = 0; j < FINAL_REG_KEYS; ++j) cw += (uint32_t)__builtin_popcountll(__ballot((uint32_t)(kr[j] >> 32) >= L));
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&s_cnt, cw);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+#pragma unroll
+            for (int j = 0; j < FINAL_REG_KEYS; ++j) {
+              const bool hit = (uint32_t)(kr[j] >> 32) >= L;
+              const unsigned long long mm = __ballot(hit);
+              if (hit) {
+                const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0));
+                if (slot < (uint32_t)SORT_CAP) S[slot] = kr[j];
+              }
+              base += (uint32_t)__builtin_popcountll(mm);
+            }
+            __syncthreads();
+            const uint32_t total = s_cnt;
+            __syncthreads();
+            if (total <= (uint32_t)SORT_CAP) {
+              m = next_pow2((int)total < 2 ? 2 : (int)total);
+              for (int i = (int)total + threadIdx.x; i < m; i += blockDim.x) S[i] = 0ull;
+              done = true;
+            } else if (threadIdx.x == 0) {
+              s_cnt = 0;
+            }
+          }
+        }
+        if (!done) {
         for (int i = threadIdx.x; i < WBINS; i += blockDim.x) lh[i] = 0;
         __syncthreads();   // s_cnt = 0 and the cleared histogram are visible
 #pragma unroll
@@ -455,7 +523,6 @@ __global__ __launch_bounds__(FINAL_THREADS) void select_final_kernel(
         __syncthreads();
         uint32_t bstar, k2;
         pick_bucket<FINAL_THREADS>(lh, WBINS, (uint32_t)count, sh, &bstar, &k2);
-        bool done = false;
         if (bstar != 0xffffffffu) {
 #pragma unroll
           for (int j = 0; j < FINAL_REG_KEYS; ++j)
@@ -471,6 +538,7 @@ __global__ __launch_bounds__(FINAL_THREADS) void select_final_kernel(
             for (int i = (int)total + threadIdx.x; i < m; i += blockDim.x) S[i] = 0ull;
             done = true;
           }
+        }
         }
         if (!done) {
           if (threadIdx.x == 0) s_cnt = 0;
@@ -503,7 +571,10 @@ __global__ __launch_bounds__(FINAL_THREADS) void select_final_kernel(
     // thread has read the header)
     __syncthreads();
     uint32_t* w = scratch + (int64_t)qi * SCR_WORDS;
-    for (int i = threadIdx.x; i < SCR_WORDS; i += blockDim.x) w[i] = 0;
+    // (mode 3: the fused epilogue touched the header only -- the 16 KiB histogram behind it is still zero; zeroing it anyway
+    //  was 16.8 MB of stores per 1024-query call)
+    const int nz = mode == 3 ? (int)(sizeof(SelHeader) / 4) : SCR_WORDS;
+    for (int i = threadIdx.x; i < nz; i += blockDim.x) w[i] = 0;
   }
   __syncthreads();
   bitonic_sort_lds_desc(S, m);
@@ -523,7 +594,7 @@ __global__ __launch_bounds__(FINAL_THREADS) void select_final_kernel(
 // A window that holds fewer than k keys (negative k-th best) or a bin with more than PK_LIST keys falls
 // back to that radix select: always exact.
 constexpr int PK_LIST = 1024;
-__global__ __launch_bounds__(FINAL_THREADS) void prefix_kth_kernel(
+__global__ __launch_bounds__(FINAL_THREADS, 4) void prefix_kth_kernel(
     const float* __restrict__ scores, int64_t n, int64_t score_stride, int k, float* __restrict__ thr) {
   __shared__ uint32_t lh[WBINS];
   __shared__ uint32_t sh[256 + 2];
@@ -551,8 +622,57 @@ __global__ __launch_bounds__(FINAL_THREADS) void prefix_kth_kernel(
       kr[4 * j + 2] = i + 2 < n ? score_key(q4.z) : 0u;
       kr[4 * j + 3] = i + 3 < n ? score_key(q4.w) : 0u;
     }
-    for (int i = threadIdx.x; i < WBINS; i += blockDim.x) lh[i] = 0;
     if (threadIdx.x == 0) s_cnt = 0;
+    // 0. (k <= 256) A lower bound without a histogram: the k-th largest of the 256 per-thread maxima is >= k keys' worth of
+    //    evidence that the k-th best is at least that large (each maximum is a different element).  The ~1.5 % of the keys
+    //    at or above it (a couple of hundred of 16,384) are listed by ballot + prefix count -- four LDS atomics per
+    //    workgroup, one per wave -- and the k-th is found among them by counting.  No scattered LDS atomics at all: the
+    //    histogram passes (half of whose LDS cycles were bank-conflict cycles, profiles/r3_cfg2_summary.json,
+    //    r4 with the window histogram: still 0.50 -- 64 random bins per wave instruction hit 32 banks) remain as the
+    //    fallback for k > 256, for keys that are mostly equal, and for prefixes with fewer than k positive keys.
+    if (k <= FINAL_THREADS) {
+      uint32_t tmax = 0;
+#pragma unroll
+      for (int j = 0; j < PK_REGS; ++j) tmax = kr[j] > tmax ? kr[j] : tmax;
+      const uint32_t L = block_kth_of_thread_values(tmax, (uint32_t)k, sh);
+      if (L != 0u) {
+        const int lane = (int)(threadIdx.x & 63);
+        uint32_t cw = 0;
+#pragma unroll
+        for (int j = 0; j < PK_REGS; ++j) cw += (uint32_t)__builtin_popcountll(__ballot(kr[j] >= L));
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&s_cnt, cw);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+#pragma unroll
+        for (int j = 0; j < PK_REGS; ++j) {
+          const bool hit = kr[j] >= L;
+          const unsigned long long m = __ballot(hit);
+          if (hit) {
+            const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+            if (slot < (uint32_t)PK_LIST) list[slot] = kr[j];
+          }
+          base += (uint32_t)__builtin_popcountll(m);
+        }
+        __syncthreads();
+        const uint32_t cnt = s_cnt;
+        if (cnt <= (uint32_t)PK_LIST) {
+          for (uint32_t t = threadIdx.x; t < cnt; t += blockDim.x) {
+            const uint32_t mine = list[t];
+            uint32_t gt = 0, ge = 0;
+            for (uint32_t u = 0; u < cnt; ++u) {
+              const uint32_t o = list[u];
+              gt += o > mine ? 1u : 0u;
+              ge += o >= mine ? 1u : 0u;
+            }
+            if (gt < (uint32_t)k && (uint32_t)k <= ge) thr[blockIdx.x] = key_score(mine);
+          }
+          return;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_cnt = 0;   // (a crowded value: the histogram passes below sort it out)
+      }
+    }
+    for (int i = threadIdx.x; i < WBINS; i += blockDim.x) lh[i] = 0;
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < PK_REGS; ++j) {

@@ -56,7 +56,7 @@ int fail(int code, const char* fmt, ...) {
 
 // ---- internal tunables (svs_internal_tune: tools and tests; not part of the ABI) --------------------
 std::atomic<int64_t> g_tune_prefix_div{64};   // fused path: rows of the threshold prefix = n / this (>= FUSE_PREFIX_MIN)
-std::atomic<int64_t> g_tune_upload{0};        // host batches: 0 = f16 / fp8 batches are PULLED from pinned memory by the staging kernels, chunk by chunk
+std::atomic<int64_t> g_tune_upload{0};        // host batches: 0 = f16 batches are PULLED from pinned memory by the staging kernel, chunk by chunk
                                               // (no DMA, no f32 copy in HBM); 1 = round 3's staging + DMA for every dtype
 thread_local double g_host_phase[6];          // svs_internal_host_phases: seconds since the call began (last svs_index_search on this thread)
 
@@ -1659,8 +1659,8 @@ static int32_t search_host(svs_index* idx, const float* queries, int32_t nq, int
   if ((rc = plan_search(idx, c, nq, count, count, c->stream, true, &plan)) != SVS_OK) return rc;
   stamp(0);
   const int64_t mode = g_tune_upload.load();
-  // f16 / fp8 batches: the staging kernel (convert_queries_f16 / quantize_rows_fp8) reads the f32 queries STRAIGHT out of
-  // the pinned buffer, over PCIe, once (fp8: twice), and writes the half / e4m3 image the GEMM kernels use -- no copy-engine
+  // f16 batches: the staging kernel (convert_queries_f16) reads the f32 queries STRAIGHT out of the pinned buffer, over
+  // PCIe, once, and writes the half image the GEMM kernels use -- no copy-engine
   // transfer, no f32 copy of the queries in HBM, no hand-over between the DMA engine and the compute queue in front of the
   // first kernel -- and it does so CHUNK BY CHUNK (<= 1 MiB of whole queries): chunk j is pulled over the bus while the host
   // copies chunk j + 1 into pinned memory.  Measured on configs[2] (6.3 MB of queries; tools/call_breakdown.py): the host copy
@@ -1668,7 +1668,9 @@ static int32_t search_host(svs_index* idx, const float* queries, int32_t nq, int
   // the first GEMM, overlapped ~0.16.  f32 indexes keep the staged DMA: their kernels read the f32 queries themselves, many
   // times.  (Also measured and dropped: helper threads sharing the host copy -- the pool's hand-offs cost what it saved,
   // 0.112 vs 0.088 ms to fill the pinned buffer; and the prefix pass per query tile, see SearchPlan.)
-  const bool pull = mode == 0 && idx->dtype != SVS_DTYPE_F32 && (uses_q16(idx, nq) || (nq >= 2 && tiled_ok(idx)));
+  // (fp8 batches stay on the staged DMA too: quantize_rows_fp8 reads its source twice -- row maximum, then the bytes -- and over
+  //  the bus that cost configs[4] 0.03-0.05 ms per call where it saved configs[2] as much)
+  const bool pull = mode == 0 && idx->dtype == SVS_DTYPE_F16 && (uses_q16(idx, nq) || (nq >= 2 && tiled_ok(idx)));
   const float* q_src = pull ? c->q_pin : c->q_dev;
   if (pull) {
     const int rows_total = staged_rows(idx, nq);
