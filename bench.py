@@ -447,7 +447,9 @@ def run_multi(args):
     out = {"metric": "queries/sec, cosine top-%d over %dx%d %s, single query" % (k, n_total, d, {"f32": "fp32", "f16": "fp16", "fp8": "fp8"}[args.dtype]),
            "value": K / elapsed, "unit": "queries/s", "n_gpus": G, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-           "config": {"workload": ("BASELINE.json configs[%d]: " % (3 if args.config == 3 else 1)) + "%d docs x dim %d %s, top-%d, single query, "
+           "config": {"workload": (("BASELINE.json configs[%d]: " % (3 if args.config == 3 else 1))
+                                   if ((args.config == 3 and args.rows == 12_500_000 and d == 1536) or (args.config == 1 and n_total == 1_000_000 and d == 1536 and args.dtype == "f32")) else "")
+                                  + "%d docs x dim %d %s, top-%d, single query, "
                                   "row-sharded over %d shards in ONE process + host merge" % (n_total, d, args.dtype, k, G),
                       "path": path, "devices": devices, "rows_per_shard": [hi - lo for lo, hi in bounds], "dim": d, "k": k},
            "roofline": {"bound": "hbm", "kernel": KERNEL_NAME[(args.dtype, 1)], "unit": "GB/s", "peak": HBM_PEAK / 1e9 * len(set(devices)),

@@ -13,7 +13,7 @@ SCORE_ATOL = 1e-5
 NEAR_TIE = 1e-6
 
 
-def assert_topk_parity(got_scores, got_rows, exp_scores, exp_rows, truth64=None, label=""):
+def assert_topk_parity(got_scores, got_rows, exp_scores, exp_rows, truth64=None, label="", score_atol=SCORE_ATOL):
     got_scores = np.asarray(got_scores, dtype=np.float64)
     exp_scores = np.asarray(exp_scores, dtype=np.float64)
     got_rows = np.asarray(got_rows, dtype=np.int64)
@@ -21,7 +21,7 @@ def assert_topk_parity(got_scores, got_rows, exp_scores, exp_rows, truth64=None,
     assert got_rows.shape == exp_rows.shape, f"{label}: count {got_rows.shape} != {exp_rows.shape}"
     if got_rows.size == 0:
         return 0
-    assert np.all(np.abs(got_scores - exp_scores) <= SCORE_ATOL), \
+    assert np.all(np.abs(got_scores - exp_scores) <= score_atol), \
         f"{label}: max score delta {np.max(np.abs(got_scores - exp_scores))}"
     # descending, ties broken by row descending
     ds = np.diff(got_scores)

@@ -88,6 +88,9 @@ int main(int argc, char** argv) {
   std::vector<uint8_t> h((size_t)64 << 20);
   fill(h, d);
   for (size_t off = 0; off < (size_t)(n * a.ldb); off += h.size()) CK(hipMemcpy(a.M + off, h.data(), std::min(h.size(), (size_t)(n * a.ldb) - off), hipMemcpyHostToDevice));
+  // GDB_ZERO=1: an all-zero corpus (timing only; the parity section still runs on it): the same instructions and the same bytes
+  // moved, but matrix-pipe operands that toggle nothing -- what the kernels do when the chip's power budget is not the limit
+  if (getenv("GDB_ZERO")) { CK(hipMemset(a.M, 0, (size_t)(n * a.ldb))); printf("corpus: all zeros\n"); }
   CK(hipMemset(a.Q, 0, (size_t)128 * a.ldb));
   CK(hipMemcpy(a.Q, h.data() + 1234560, (size_t)nq * a.ldb, hipMemcpyHostToDevice));
   CK(hipMalloc(&a.st, (size_t)128 * SCR_WORDS * 4)); CK(hipMalloc(&a.cand, (size_t)128 * CAND_CAP * 8));

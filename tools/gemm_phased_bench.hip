@@ -98,6 +98,9 @@ int run(int64_t n, int d, int nq, int rounds) {
     }
   }
   for (size_t off = 0; off < (size_t)(n * a.ldb); off += h.size()) CK(hipMemcpy(a.M + off, h.data(), std::min(h.size(), (size_t)(n * a.ldb) - off), hipMemcpyHostToDevice));
+  // PGB_ZERO=1 (round 4): an all-zero corpus -- the same instructions and bytes, matrix-pipe operands that toggle nothing: the
+  // kernels' speed when the chip's power budget is not what limits them (timing only)
+  if (getenv("PGB_ZERO")) { CK(hipMemset(a.M, 0, (size_t)(n * a.ldb))); printf("corpus: all zeros\n"); }
   CK(hipMemcpy(a.Q, h.data() + 12346, (size_t)nq_pad * a.ldb, hipMemcpyHostToDevice));   // (an EVEN offset: the exponent mask sits on the odd bytes; an odd one fills the queries with inf / NaN)
   CK(hipMalloc(&a.st, (size_t)nq * SCR_WORDS * 4)); CK(hipMemset(a.st, 0, (size_t)nq * SCR_WORDS * 4));
   CK(hipMalloc(&a.cand, (size_t)nq * CAND_CAP * 8)); CK(hipMalloc(&a.thr, nq * 4)); CK(hipMalloc(&a.rs, n * 4)); CK(hipMemset(a.rs, 0, n * 4));
