@@ -378,19 +378,17 @@ int stage_queries_f16(const svs_index* idx, Ctx* c, const float* q, int nq, int 
 
 // quantises nq f32 queries to e4m3 into c->q8 ([rows_alloc][ld] bytes, rows >= nq zero) with
 // scales c->q8s; want_f32 also fills c->q8f with the quantised values as f32
-int stage_queries_fp8(const svs_index* idx, Ctx* c, const float* q, int nq, int rows_alloc, bool want_f32, hipStream_t st, int row0 = 0) {
+int stage_queries_fp8(const svs_index* idx, Ctx* c, const float* q, int nq, int rows_alloc, bool want_f32, hipStream_t st) {
   int rc;
-  const size_t o = (size_t)row0;
   if ((rc = grow_dev(&c->q8, &c->q8_cap, (size_t)rows_alloc * idx->ld)) != SVS_OK) return rc;
   if ((rc = grow_dev(&c->q8s, &c->q8s_cap, (size_t)rows_alloc)) != SVS_OK) return rc;
   if (want_f32 && (rc = grow_dev(&c->q8f, &c->q8f_cap, (size_t)rows_alloc * idx->ld)) != SVS_OK) return rc;
-  rows_alloc -= row0;
-  if (rows_alloc > nq) {
-    HIP_TRY(hipMemsetAsync(c->q8 + (o + nq) * idx->ld, 0, (size_t)(rows_alloc - nq) * idx->ld, st));
-    HIP_TRY(hipMemsetAsync(c->q8s + o + nq, 0, (size_t)(rows_alloc - nq) * sizeof(float), st));
+  if (rows_alloc > nq) {   // (the kernel writes whole padded rows: only the rows behind the queries need zeroing)
+    HIP_TRY(hipMemsetAsync(c->q8 + (size_t)nq * idx->ld, 0, (size_t)(rows_alloc - nq) * idx->ld, st));
+    HIP_TRY(hipMemsetAsync(c->q8s + nq, 0, (size_t)(rows_alloc - nq) * sizeof(float), st));
   }
   hipLaunchKernelGGL(quantize_rows_fp8_kernel, dim3((nq + 3) / 4), dim3(256), 0, st, q, (int64_t)nq, idx->d, (int64_t)idx->d,
-                     c->q8 + o * idx->ld, idx->ld, c->q8s + o, want_f32 ? c->q8f + o * idx->ld : (float*)nullptr);
+                     c->q8, idx->ld, c->q8s, want_f32 ? c->q8f : (float*)nullptr);
   return SVS_OK;
 }
 
@@ -1659,36 +1657,28 @@ static int32_t search_host(svs_index* idx, const float* queries, int32_t nq, int
   if ((rc = plan_search(idx, c, nq, count, count, c->stream, true, &plan)) != SVS_OK) return rc;
   stamp(0);
   const int64_t mode = g_tune_upload.load();
-  // f16 batches: the staging kernel (convert_queries_f16) reads the f32 queries STRAIGHT out of the pinned buffer, over
-  // PCIe, once, and writes the half image the GEMM kernels use -- no copy-engine
-  // transfer, no f32 copy of the queries in HBM, no hand-over between the DMA engine and the compute queue in front of the
-  // first kernel -- and it does so CHUNK BY CHUNK (<= 1 MiB of whole queries): chunk j is pulled over the bus while the host
-  // copies chunk j + 1 into pinned memory.  Measured on configs[2] (6.3 MB of queries; tools/call_breakdown.py): the host copy
-  // takes 0.15 ms, the bus 0.13 ms whichever engine drives it; one after the other (round 3) they cost 0.28 ms in front of
-  // the first GEMM, overlapped ~0.16.  f32 indexes keep the staged DMA: their kernels read the f32 queries themselves, many
-  // times.  (Also measured and dropped: helper threads sharing the host copy -- the pool's hand-offs cost what it saved,
-  // 0.112 vs 0.088 ms to fill the pinned buffer; and the prefix pass per query tile, see SearchPlan.)
-  // (fp8 batches stay on the staged DMA too: quantize_rows_fp8 reads its source twice -- row maximum, then the bytes -- and over
-  //  the bus that cost configs[4] 0.03-0.05 ms per call where it saved configs[2] as much)
+  // f16 batches: the staging kernel (convert_queries_f16) reads the f32 queries STRAIGHT out of the pinned buffer, over PCIe,
+  // once, and writes the half image the GEMM kernels use -- no copy-engine transfer, no f32 copy of the queries in HBM, no
+  // hand-over between the DMA engine and the compute queue in front of the first kernel -- CHUNK BY CHUNK (<= 1 MiB of whole
+  // queries): chunk j is pulled over the bus while the host copies chunk j + 1 into pinned memory.  Measured on configs[2]
+  // (6.3 MB of queries; tools/call_breakdown.py): 0.088 ms until everything is enqueued against 0.15 with the DMA calls in
+  // between.  f32 indexes keep the staged DMA (their kernels read the f32 queries themselves, many times), and so do fp8
+  // ones: quantize_rows_fp8 reads its source twice -- row maximum, then the bytes -- and over the bus that cost configs[4]
+  // 0.03-0.05 ms per call.  (Also measured and dropped: helper threads sharing the host copy -- their hand-offs cost what
+  // they saved, 0.112 vs 0.088 ms to fill the pinned buffer; and the prefix pass per query tile, see SearchPlan.)
   const bool pull = mode == 0 && idx->dtype == SVS_DTYPE_F16 && (uses_q16(idx, nq) || (nq >= 2 && tiled_ok(idx)));
   const float* q_src = pull ? c->q_pin : c->q_dev;
   if (pull) {
-    const int rows_total = staged_rows(idx, nq);
+    const int rows_total = staged_rows(idx, nq);            // the image of the WHOLE batch: sized once, before the first chunk
+    rc = grow_dev(&c->qh, &c->qh_cap, (size_t)rows_total * idx->ld);
     int cq = 256;                                           // queries per chunk: <= 1 MiB, a power of two
     while (cq > 1 && (size_t)cq * d * sizeof(float) > ((size_t)1 << 20)) cq >>= 1;
     for (int q0 = 0; q0 < nq && rc == SVS_OK; q0 += cq) {
       const int nc = std::min(cq, nq - q0);
       const size_t off = (size_t)q0 * d;
       memcpy(c->q_pin + off, queries + off, (size_t)nc * d * sizeof(float));
-      // (rows_total on every call: the first sizes the image for the whole batch, the last zeroes its padding rows)
-      const int upto = q0 + nc == nq ? rows_total : q0 + nc;
-      if (q0 == 0 && upto < rows_total)   // size the image once, for the whole batch
-        rc = idx->dtype == SVS_DTYPE_F16 ? grow_dev(&c->qh, &c->qh_cap, (size_t)rows_total * idx->ld)
-                                         : ((rc = grow_dev(&c->q8, &c->q8_cap, (size_t)rows_total * idx->ld)) != SVS_OK ? rc
-                                                : grow_dev(&c->q8s, &c->q8s_cap, (size_t)rows_total));
-      if (rc == SVS_OK)
-        rc = idx->dtype == SVS_DTYPE_F16 ? stage_queries_f16(idx, c, c->q_pin + off, nc, upto, c->stream, q0)
-                                         : stage_queries_fp8(idx, c, c->q_pin + off, nc, upto, false, c->stream, q0);
+      // (rows [q0, q0 + nc) of the image; the last chunk also zeroes the padding rows behind the batch)
+      rc = stage_queries_f16(idx, c, c->q_pin + off, nc, q0 + nc == nq ? rows_total : q0 + nc, c->stream, q0);
     }
     plan.staged = true;
   } else {
