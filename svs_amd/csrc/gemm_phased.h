@@ -419,7 +419,7 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
                                 : (QT == 256 ? wr * 32 + jj * 128 + (kind >> 1) * 32 : (wave >> 1) * 16 + (kind >> 1) * 16);
     const int vo = tm ? pg_voff(vbase_tm, rows * TG_BKB) : pg_voff(il ? vbase_tm : vbase, rows * ldb);
     const unsigned dst = pg_lds_dest<slot * PG_SLOT * 16 + jj * 8192>(wave_lds);
-    if constexpr ((EXP == 20 || EXP == 40 || EXP == 45 || EXP == 52 || EXP == 41 || EXP == 46) && (kind & 1))   // (corpus rows nontemporal: the single-query-tile form, see launch_tiled_eb)
+    if constexpr ((EXP == 20 || EXP == 40 || EXP == 45 || EXP == 52 || EXP == 41 || EXP == 46 || EXP == 62 || EXP == 63) && (kind & 1))   // (corpus rows nontemporal: the single-query-tile form, see launch_tiled_eb)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(uintptr_t)dst, 16, vo, soff, 0, 2);
     else
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(uintptr_t)dst, 16, vo, soff, 0, 0);
@@ -468,42 +468,58 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
   // s0 / s1: the phase's two LDS-DMA pieces when they are issued BETWEEN the MFMAs (kDmaInMma)
   auto mma = [&](auto I, auto J, const u32x4 (&fb)[NTQ][2], auto&& s0, auto&& s1) __attribute__((always_inline)) {
     constexpr int i = decltype(I)::value, j = decltype(J)::value;
+    // (kOrder, timing experiments 60-63: the order of a quadrant's MFMAs.  0: corpus fragment outer, query fragment inner;
+    //  1: the same as a snake -- ONE operand changes from each MFMA to the next; 2: query fragment outer, snake over the corpus
+    //  fragments)
+    constexpr int kOrder = (EXP == 60 || EXP == 62) ? 1 : ((EXP == 61 || EXP == 63) ? 2 : 0);
+    auto step_of = [](int s, int* mt, int* nt) __attribute__((always_inline)) {
+      if (kOrder == 2) { *nt = s / 4; *mt = (*nt & 1) ? 3 - s % 4 : s % 4; }
+      else { *mt = s / NTQ; *nt = (kOrder == 1 && (*mt & 1)) ? NTQ - 1 - s % NTQ : s % NTQ; }
+    };
     if constexpr (EB == 2) {
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-#pragma unroll
-          for (int nt = 0; nt < NTQ; ++nt)
-            acc[i * 4 + mt][j * NTQ + nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
-                __builtin_bit_cast(h8, fa[mt][h]), __builtin_bit_cast(h8, fb[nt][h]), acc[i * 4 + mt][j * NTQ + nt], 0, 0, 0);
+        for (int s = 0; s < 4 * NTQ; ++s) {
+          int mt, nt;
+          step_of(s, &mt, &nt);
+          acc[i * 4 + mt][j * NTQ + nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+              __builtin_bit_cast(h8, fa[mt][h]), __builtin_bit_cast(h8, fb[nt][h]), acc[i * 4 + mt][j * NTQ + nt], 0, 0, 0);
+          if (s % NTQ != NTQ - 1) continue;
+          const int grp = s / NTQ;   // (0 .. 3: after every NTQ-th MFMA)
 #if PG_DMA_STAGGER
           // the four waves of a group share the CU's vector-memory front end (64 B/clk: 16 cycles per
           // piece): wave wc issues after MFMA pair wc, so no piece queues behind another wave's
-          if (wc == mt) {
+          if (wc == grp) {
             __builtin_amdgcn_sched_barrier(0);
             if (h == 0) s0(); else s1();
             __builtin_amdgcn_sched_barrier(0);
           }
 #else
-          if (h == 0 && mt == PG_DMA_AT0) { __builtin_amdgcn_sched_barrier(0); s0(); __builtin_amdgcn_sched_barrier(0); }
-          if (h == 1 && mt == PG_DMA_AT1) { __builtin_amdgcn_sched_barrier(0); s1(); __builtin_amdgcn_sched_barrier(0); }
+          if (h == 0 && grp == PG_DMA_AT0) { __builtin_amdgcn_sched_barrier(0); s0(); __builtin_amdgcn_sched_barrier(0); }
+          if (h == 1 && grp == PG_DMA_AT1) { __builtin_amdgcn_sched_barrier(0); s1(); __builtin_amdgcn_sched_barrier(0); }
 #endif
         }
     } else {
+      i32x8 x[4], y[NTQ];
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         const u32x4 al = fa[mt][0], ah = fa[mt][1];
-        const i32x8 x = {(int)al.x, (int)al.y, (int)al.z, (int)al.w, (int)ah.x, (int)ah.y, (int)ah.z, (int)ah.w};
+        x[mt] = (i32x8){(int)al.x, (int)al.y, (int)al.z, (int)al.w, (int)ah.x, (int)ah.y, (int)ah.z, (int)ah.w};
+      }
 #pragma unroll
-        for (int nt = 0; nt < NTQ; ++nt) {
-          const u32x4 bl = fb[nt][0], bh = fb[nt][1];
-          const i32x8 y = {(int)bl.x, (int)bl.y, (int)bl.z, (int)bl.w, (int)bh.x, (int)bh.y, (int)bh.z, (int)bh.w};
-          acc[i * 4 + mt][j * NTQ + nt] =
-              __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(x, y, acc[i * 4 + mt][j * NTQ + nt], 0, 0, 0, 0, 0, 0);
-        }
-        if (mt == 0) { __builtin_amdgcn_sched_barrier(0); s0(); __builtin_amdgcn_sched_barrier(0); }
-        if (mt == 2) { __builtin_amdgcn_sched_barrier(0); s1(); __builtin_amdgcn_sched_barrier(0); }
+      for (int nt = 0; nt < NTQ; ++nt) {
+        const u32x4 bl = fb[nt][0], bh = fb[nt][1];
+        y[nt] = (i32x8){(int)bl.x, (int)bl.y, (int)bl.z, (int)bl.w, (int)bh.x, (int)bh.y, (int)bh.z, (int)bh.w};
+      }
+#pragma unroll
+      for (int s = 0; s < 4 * NTQ; ++s) {
+        int mt, nt;
+        step_of(s, &mt, &nt);
+        acc[i * 4 + mt][j * NTQ + nt] =
+            __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(x[mt], y[nt], acc[i * 4 + mt][j * NTQ + nt], 0, 0, 0, 0, 0, 0);
+        if (s == NTQ - 1) { __builtin_amdgcn_sched_barrier(0); s0(); __builtin_amdgcn_sched_barrier(0); }
+        if (s == 3 * NTQ - 1) { __builtin_amdgcn_sched_barrier(0); s1(); __builtin_amdgcn_sched_barrier(0); }
       }
     }
   };

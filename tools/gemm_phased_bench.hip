@@ -129,6 +129,10 @@ int run(int64_t n, int d, int nq, int rounds) {
                   {"phased QT=128, default policy", launch_phased<EB, 0, 128>}, {"phased QT=128, no epilogue", launch_phased<EB, 14, 128>},
                   {"phased QT=128, LDS-DMA + barriers only", launch_phased<EB, 5, 128>}, {"phased QT=128, tile-major, LDS-DMA + barriers only", launch_phased<EB, 45, 128>},
                   {"phased QT=128, 8-row-interleaved image (timing only)", launch_phased<EB, 41, 128>}, {"phased QT=128, 8-row-interleaved, LDS-DMA + barriers only", launch_phased<EB, 46, 128>}};
+#elif defined(PGB_ORDER)   // round 4: the order of a quadrant's MFMAs (which operand changes from one MFMA to the next): an energy question
+  const V vs[] = {{"round-1 tiled 256x256 (reference only)", launch_tiled<EB>}, {"phased (corpus fragment outer: what ships for f16)", launch_phased<EB, 0>},
+                  {"phased, snake: one operand changes per MFMA", launch_phased<EB, 60>}, {"phased, query fragment outer, snake", launch_phased<EB, 61>},
+                  {"phased nt (what ships for fp8)", launch_phased<EB, 20>}, {"phased nt, snake", launch_phased<EB, 62>}, {"phased nt, query fragment outer, snake", launch_phased<EB, 63>}};
 #elif defined(PGB_FULL)   // every ablation (slow to compile: fourteen instantiations per operand type)
   const V vs[] = {{"round-1 tiled 256x256", launch_tiled<EB>}, {"phased", launch_phased<EB, 0>}, {"phased, no LDS-DMA in loop", launch_phased<EB, 1>},
                   {"phased, no fragment reads", launch_phased<EB, 2>}, {"phased, no MFMA", launch_phased<EB, 3>},
