@@ -294,6 +294,35 @@ __device__ __forceinline__ void emit_topk(const uint64_t* S, int count, int k, i
   }
 }
 
+// Lists of up to one key per thread (m <= blockDim.x): ordered WITHOUT sorting.  Real keys are unique (the row number
+// is their low half), so a key's position in the descending order is the number of keys above it: every thread
+// counts that for its own key over the whole list -- 16-byte LDS reads of ONE address by all lanes (a broadcast:
+// no bank conflicts, no barrier between the steps) -- and stores its answer where it belongs.  A bitonic network
+// over the same 256 slots is 36 barrier-separated compare-exchange steps whose 8-byte accesses at strides 1-16
+// collide pairwise (28 % of select_final_kernel's LDS cycles in round 4's counter pass); this is one pass.
+// Keys equal to 0 are padding or struck-out candidates (a real key is never 0) and are not emitted; positions from
+// the number of real keys (>= count in every mode: see the callers) up to k are filled as emit_topk fills them.
+__device__ __forceinline__ void emit_by_rank(const uint64_t* S, int m, int count, int k, int64_t row_offset,
+                                             float* __restrict__ out_scores, int64_t* __restrict__ out_rows) {
+  const uint64_t a = (int)threadIdx.x < m ? S[threadIdx.x] : 0ull;
+  const ulonglong2* S2 = reinterpret_cast<const ulonglong2*>(S);
+  int above = 0;
+#pragma unroll 4
+  for (int j = 0; j < (m >> 1); ++j) {
+    const ulonglong2 p = S2[j];
+    above += (p.x > a ? 1 : 0) + (p.y > a ? 1 : 0);
+  }
+  const int n_real = __syncthreads_count(a != 0ull);
+  if (a != 0ull && above < count) {
+    out_scores[above] = key_score((uint32_t)(a >> 32));
+    out_rows[above] = row_offset + (int64_t)(uint32_t)a;
+  }
+  for (int i = (n_real < count ? n_real : count) + (int)threadIdx.x; i < k; i += blockDim.x) {
+    out_scores[i] = -__builtin_inff();
+    out_rows[i] = -1;
+  }
+}
+
 // One workgroup: exact k-th largest of the M unique 64-bit keys key_at(0..M),
 // Histogram increment with the wave's dominant bin aggregated: candidate keys of one query share their
 // leading bits, so in the upper radix passes (and for the bulk of a prefix's scores) most lanes of a wave hit
@@ -401,7 +430,7 @@ __global__ __launch_bounds__(FINAL_THREADS) void select_final_kernel(
     int mode, uint32_t* __restrict__ scratch, uint64_t* cand,
     int64_t row_offset, float* __restrict__ out_scores, int64_t* __restrict__ out_rows,
     const uint32_t* __restrict__ dead_bits = nullptr) {
-  __shared__ uint64_t S[SORT_CAP];
+  __shared__ __attribute__((aligned(16))) uint64_t S[SORT_CAP];
   __shared__ uint32_t lh[WBINS];   // window histogram (WBINS) or radix-select histogram (RS_BINS <= WBINS)
   __shared__ uint32_t sh[256 + 2];
   __shared__ uint32_t s_cnt;
@@ -577,8 +606,12 @@ __global__ __launch_bounds__(FINAL_THREADS) void select_final_kernel(
     for (int i = threadIdx.x; i < nz; i += blockDim.x) w[i] = 0;
   }
   __syncthreads();
-  bitonic_sort_lds_desc(S, m);
-  emit_topk(S, count, k_out, row_offset, os, orow);
+  if (m <= FINAL_THREADS) {   // the usual case: k = 100 leaves 120-200 keys here on every route
+    emit_by_rank(S, m, count, k_out, row_offset, os, orow);
+  } else {
+    bitonic_sort_lds_desc(S, m);
+    emit_topk(S, count, k_out, row_offset, os, orow);
+  }
 }
 
 // ---- fused path, thresholds: thr[q] = exact k-th best score of scores[q][0 .. n) ----

@@ -101,8 +101,14 @@ def test_append_while_searching(gpu):
             for it in range(60):
                 for qi, q in enumerate(qs):
                     r = idx.search(q, 30)
-                    mid_ok = all(row < idx.n for _, row in r)
-                    assert mid_ok
+                    # (not `row < idx.n`: the Python attribute is refreshed AFTER svs_index_append returns, so a search
+                    #  that runs in between rightly reports rows the attribute does not cover yet.  What must hold for
+                    #  either corpus: a real row of the final matrix, with that row's own score, best first.)
+                    rows = np.array([row for _, row in r])
+                    sc = np.array([s for s, _ in r], dtype=np.float64)
+                    assert len(r) == 30 and (rows >= 0).all() and (rows < len(m)).all() and len(set(rows.tolist())) == 30
+                    assert np.abs(m[rows].astype(np.float64) @ q.astype(np.float64) - sc).max() < 1e-5
+                    assert (np.diff(sc) <= 0).all()
         except Exception as e:   # noqa: BLE001
             errs.append(e)
 
