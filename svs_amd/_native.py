@@ -96,6 +96,13 @@ INTERNAL = {
 }
 
 _lib: Optional[C.CDLL] = None
+_quick: Optional[C.PyDLL] = None
+
+# Entry points that neither block nor take a lock (a few loads, or one atomic add): bound a second time through
+# PyDLL, which keeps the GIL across the call.  CDLL drops and re-takes it around EVERY call, and with many Python
+# threads inside retrieve() each re-take is a hand-off (futex wake + context switch, 5-10 us in which no thread
+# runs Python): four of them per search -- info, retain, search, release -- against one (the search itself).
+QUICK = ("svs_index_info", "svs_index_retain", "svs_index_release", "svs_last_error", "svs_multi_info")
 
 
 def lib_path() -> str:
@@ -146,8 +153,25 @@ def load() -> C.CDLL:
     return lib
 
 
+def quick():
+    """The same library bound through PyDLL, for the entry points in QUICK (see there).  svs_index_release through
+    this binding is for a reference taken around ONE call (the owner still holds its own, so it is not the last and
+    frees nothing); an owner's release -- which may free gigabytes of HBM -- goes through load()."""
+    global _quick
+    if _quick is not None:
+        return _quick
+    load()
+    # (SVS_AMD_QUICK=0: the GIL-releasing binding for these too -- the A/B of tools/coalesce_bench.py)
+    ql = C.PyDLL(_LIB_PATH) if os.environ.get("SVS_AMD_QUICK", "1") != "0" else C.CDLL(_LIB_PATH)
+    for name in QUICK:
+        fn = getattr(ql, name)
+        fn.restype, fn.argtypes = SIGNATURES[name]
+    _quick = ql
+    return ql
+
+
 def last_error() -> str:
-    return (load().svs_last_error() or b"").decode("utf-8", "replace")
+    return (quick().svs_last_error() or b"").decode("utf-8", "replace")   # (thread-local in the library: same thread, no hand-off)
 
 
 def check(rc: int) -> None:

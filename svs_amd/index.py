@@ -34,6 +34,7 @@ class DeviceIndex:
     def __init__(self, matrix: Optional[np.ndarray], device: int = 0, row_offset: int = 0,
                  dtype: str = "f32", *, _handle: Optional[int] = None):
         self._lib = _native.load()
+        self._quick = _native.quick()   # info / retain / release of a per-call reference: under the GIL (see _native.QUICK)
         self._lock = threading.Lock()
         self._h: Optional[int] = None
         if _handle is not None:
@@ -108,7 +109,7 @@ class DeviceIndex:
         """Rows a search can return right now (the handle may have been appended to or
         masked through another owner since this object last looked)."""
         info = _native.IndexInfo()
-        _native.check(self._lib.svs_index_info(self._handle(), C.byref(info)))
+        _native.check(self._quick.svs_index_info(self._handle(), C.byref(info)))
         return max(int(info.n) - int(info.n_masked), 0)
 
     def _pinned_handle(self) -> int:
@@ -116,8 +117,12 @@ class DeviceIndex:
         handle between reading it and entering the library."""
         with self._lock:
             h = self._handle()
-            self._lib.svs_index_retain(h)
+            self._quick.svs_index_retain(h)
             return h
+
+    def _unpin(self, h: int) -> None:
+        """Drops the reference _pinned_handle() took (normally not the last one: the owner holds its own)."""
+        self._quick.svs_index_release(h)
 
     # -- incremental update (SURVEY.md 8(f) rank 4) ---------------------------------
     def append(self, matrix: np.ndarray) -> None:
@@ -194,21 +199,24 @@ class DeviceIndex:
         if q.ndim != 2:
             raise ValueError(f"queries must be 2-D, got shape {q.shape}")
         nq, d = q.shape
-        # clamp before allocating and before the int32 argument (reference src/svs/util.py:198-199
-        # clamps top_k to len(scores) first): k = 2**32 must mean "rank everything", not 0
-        k = min(max(n, 0), self._live_rows())
-        scores = np.empty((nq, k), dtype=np.float32)
-        rows = np.empty((nq, k), dtype=np.int64)
-        count = C.c_int32(0)
         h = self._pinned_handle()
         try:
-            _native.check(self._lib.svs_index_search(
-                h, q.ctypes.data_as(C.c_void_p), nq, d, k,
-                scores.ctypes.data_as(C.c_void_p), rows.ctypes.data_as(C.c_void_p), C.byref(count)))
+            # clamp before allocating and before the int32 argument (reference src/svs/util.py:198-199
+            # clamps top_k to len(scores) first): k = 2**32 must mean "rank everything", not 0.  (The row count is
+            # read through the pinned handle: the index may have been appended to or masked through another owner.)
+            info = _native.IndexInfo()
+            _native.check(self._quick.svs_index_info(h, C.byref(info)))
+            k = min(max(n, 0), max(int(info.n) - int(info.n_masked), 0))
+            scores = np.empty((nq, k), dtype=np.float32)
+            rows = np.empty((nq, k), dtype=np.int64)
+            count = C.c_int32(0)
+            # (the one call of a search that releases the GIL)
+            _native.check(self._lib.svs_index_search(h, q.ctypes.data, nq, d, k, scores.ctypes.data, rows.ctypes.data,
+                                                     C.byref(count)))
         finally:
-            self._lib.svs_index_release(h)
+            self._unpin(h)
         c = count.value
-        return scores[:, :c], rows[:, :c]
+        return (scores, rows) if c == k else (scores[:, :c], rows[:, :c])
 
     def search(self, query_vec: np.ndarray, n: int) -> List[Tuple[float, int]]:
         """``get_top_k(np.dot(M, query_vec), n)``: list of (score, row index),
@@ -245,7 +253,7 @@ class DeviceIndex:
             _native.check(rc)
             raise RuntimeError("svs_index_scores_n: the index kept growing")
         finally:
-            self._lib.svs_index_release(h)
+            self._unpin(h)
 
     def search_device(self, q_ptr: int, nq: int, d: int, k: int, out_scores_ptr: int,
                       out_rows_ptr: int, stream: int = 0) -> int:
@@ -257,7 +265,7 @@ class DeviceIndex:
                 h, C.c_void_p(q_ptr), int(nq), int(d), int(k), C.c_void_p(out_scores_ptr),
                 C.c_void_p(out_rows_ptr), C.byref(count), C.c_void_p(stream)))
         finally:
-            self._lib.svs_index_release(h)
+            self._unpin(h)
         return count.value
 
     def top_pairs(self, n: int) -> List[Tuple[float, int, int]]:
@@ -276,7 +284,7 @@ class DeviceIndex:
                 h, k, scores.ctypes.data_as(C.c_void_p), ri.ctypes.data_as(C.c_void_p),
                 rj.ctypes.data_as(C.c_void_p), C.byref(count)))
         finally:
-            self._lib.svs_index_release(h)
+            self._unpin(h)
         c = count.value
         return [(float(s), int(a), int(b)) for s, a, b in zip(scores[:c], ri[:c], rj[:c])]
 

@@ -201,7 +201,8 @@ class NativeMultiIndex:
     def _info(self):
         C = self._C
         g, n, d, dead = C.c_int32(), C.c_int64(), C.c_int32(), C.c_int64()
-        self._native.check(self._lib.svs_multi_info(self._h, C.byref(g), C.byref(n), C.byref(d), C.byref(dead)))
+        # (through the GIL-holding binding: a few loads, no lock -- _native.QUICK)
+        self._native.check(self._native.quick().svs_multi_info(self._h, C.byref(g), C.byref(n), C.byref(d), C.byref(dead)))
         return g.value, n.value, d.value, dead.value
 
     @property

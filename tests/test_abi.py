@@ -184,3 +184,20 @@ def test_internal_hooks_are_exported_but_not_in_the_public_header():
         assert s not in public, s
     assert not hasattr(lib, "svs_index_coalesce_hold")
     assert not hasattr(lib, "svs_index_scores"), "the capacity-less entry must be gone (its binding must fail at load time)"
+
+
+def test_quick_binding_keeps_the_gil_and_is_the_same_library():
+    """svs_amd/_native.py QUICK: the lock-free bookkeeping entry points of a search are bound a second time through
+    PyDLL (no GIL hand-off around them).  Same library, same thread-local error state; only entry points that cannot
+    block may be on that list."""
+    import ctypes as C
+    ql = _native.quick()
+    assert isinstance(ql, C.PyDLL) and ql is _native.quick()
+    for name in _native.QUICK:
+        assert name in _native.SIGNATURES and getattr(ql, name).argtypes == _native.SIGNATURES[name][1]
+    # whatever may wait for the device, a lock or another thread stays on the GIL-releasing binding
+    assert not {"svs_index_search", "svs_multi_search", "svs_index_append", "svs_index_create", "svs_index_scores_n"} & set(_native.QUICK)
+    info = _native.IndexInfo()
+    assert ql.svs_index_info(None, C.byref(info)) == _native.SVS_ERR_INVALID
+    assert "null" in _native.last_error()                                   # read through the quick binding ...
+    assert b"null" in (_native.load().svs_last_error() or b"")              # ... and the same state through the other

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Throughput of CONCURRENT single-query searches (what a server's AsyncKB.retrieve tasks do: one
 executor thread each, reference src/svs/kb.py:1184-1190) with and without the search coalescer.
-usage: coalesce_bench.py [n=1000000] [d=1536] [dtype=f32] [threads=1,4,16,64] [seconds=3]"""
+usage: coalesce_bench.py [n=1000000] [d=1536] [dtype=f32] [threads=1,4,16,64] [seconds=3] [modes=solo,coalesced,native]
+(SVS_AMD_QUICK=0: the bookkeeping calls of a search through the GIL-releasing binding as well -- svs_amd/_native.py QUICK)"""
 import sys, os, time, threading
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -12,6 +13,7 @@ d = int(sys.argv[2]) if len(sys.argv) > 2 else 1536
 dtype = sys.argv[3] if len(sys.argv) > 3 else "f32"
 threads = [int(x) for x in (sys.argv[4] if len(sys.argv) > 4 else "1,4,16,64").split(",")]
 secs = float(sys.argv[5]) if len(sys.argv) > 5 else 3.0
+modes = (sys.argv[6] if len(sys.argv) > 6 else "solo,coalesced,native").split(",")
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev); g.manual_seed(11)
 idx = DeviceIndex.empty(d, device=0, dtype=dtype, reserve=n)
@@ -21,7 +23,7 @@ for r0 in range(0, n, 250000):
 qs = torch.randn((256, d), device=dev, generator=g); qs /= qs.norm(dim=1, keepdim=True)
 qh = qs.cpu().numpy()
 for T in threads:
-    for mode in ("solo", "coalesced", "native"):
+    for mode in modes:
         co = SearchCoalescer() if mode == "coalesced" else None
         idx.set_coalesce(mode == "native")
         p0, q0 = idx.coalesce_stats()
