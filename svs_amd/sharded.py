@@ -196,19 +196,24 @@ class ShardedIndex:
              "host": torch.zeros((nchunks, self.world, g * rec), dtype=torch.uint8, pin_memory=True),
              "local": None if not self._multi else torch.zeros((nchunks, g * rec), device=dev, dtype=torch.uint8),
              "gathered": None if not self._multi else torch.zeros((nchunks, self.world, g * rec), device=dev, dtype=torch.uint8),
-             "streams": [torch.cuda.Stream(device=dev) for _ in range(self._n_streams)]}
+             "streams": [torch.cuda.Stream(device=dev) for _ in range(self._n_streams)],
+             # the exchange has a stream of its own: issued on a search stream (rounds 1-3) that stream's next searches
+             # sat behind the collective and the copy home -- ~120 us per exchange with one of two streams stalled,
+             # 15 us per step at one GPU's share of the 8-GPU strong-scaling run (125 k rows: 0.131 -> see DESIGN 6)
+             "xstream": None if not self._multi else torch.cuda.Stream(device=dev)}
         self._pipe = p
 
     def _send_chunk(self, c: int, st) -> None:
-        """One all-gather for chunk c (its records were written on every stream), issued on `st`."""
+        """One all-gather for chunk c (its records were written on every search stream), issued on the exchange
+        stream behind an event on each of them; the search streams go on with the next chunk's buffers."""
         import torch
         p = self._pipe
+        xs = p["xstream"]
         for o in p["streams"]:
-            if o is not st:
-                e = torch.cuda.Event()
-                e.record(o)
-                st.wait_event(e)
-        with torch.cuda.stream(st):
+            e = torch.cuda.Event()
+            e.record(o)
+            xs.wait_event(e)
+        with torch.cuda.stream(xs):
             w = self._dist.all_gather_into_tensor(p["gathered"][c].view(-1), p["local"][c], group=self.group, async_op=True)
             w.wait()    # orders this stream behind the collective; does not block the host
             if self.rank == self.dst:
