@@ -46,15 +46,34 @@ def merge_topk(scores: np.ndarray, rows: np.ndarray, k: int) -> Tuple[np.ndarray
 
 def merge_topk_batch(scores: np.ndarray, rows: np.ndarray, k: int) -> Tuple[np.ndarray, np.ndarray]:
     """``merge_topk`` for nq queries at once: ``scores``/``rows`` are (G, nq, k') candidate lists
-    (padding entries: score -inf, row -1).  ONE lexsort over the (nq, G*k') table instead of nq
-    Python-level sorts.  Returns (nq, k) arrays; requires every query to have >= k live candidates
-    (true whenever k <= rows in the corpus: each shard returns min(k', its rows))."""
+    (padding entries: score -inf, row -1).  Returns (nq, k) arrays; requires every query to have >= k live
+    candidates (true whenever k <= rows in the corpus: each shard returns min(k', its rows)).
+
+    Global rows below 2^32 (every corpus the keyed GPU paths take): the candidates are ordered the way the kernels
+    order them -- ONE sort of 64-bit keys, orderable score bits above the row (csrc/keys.h) -- 10 us per query for
+    8 x 100 candidates where a two-key ``np.lexsort`` takes 56-82 us; beyond, the lexsort."""
     g, nq, kk = scores.shape
     sc = np.ascontiguousarray(np.transpose(scores, (1, 0, 2))).reshape(nq, g * kk).astype(np.float32, copy=False)
     rw = np.ascontiguousarray(np.transpose(rows, (1, 0, 2))).reshape(nq, g * kk).astype(np.int64, copy=False)
-    key = sc + np.float32(0.0)                      # -0.0 == +0.0 (python compares them equal)
+    k = max(k, 0)
+    if rw.size and int(rw.max()) < (1 << 32):
+        b = (sc + np.float32(0.0)).view(np.uint32)                    # -0.0 == +0.0 (python compares them equal)
+        key32 = np.where(b >> 31, ~b, b | np.uint32(0x80000000))      # larger float <=> larger key
+        nan = np.isnan(sc)
+        if nan.any():
+            key32[nan] = np.uint32(0xFFFFFFFF)                        # any NaN on top (np.argpartition sorts NaN last == largest), as keys.h
+        key = (key32.astype(np.uint64) << np.uint64(32)) | (rw.astype(np.uint64) & np.uint64(0xFFFFFFFF))
+        key[rw < 0] = 0                                               # padding loses against every real row
+        key.sort(axis=1)
+        top = key[:, ::-1][:, :k]
+        k32 = (top >> np.uint64(32)).astype(np.uint32)
+        bits = np.where(k32 >> 31, k32 & np.uint32(0x7FFFFFFF), ~k32)
+        bits[k32 == np.uint32(0xFFFFFFFF)] = np.uint32(0x7FC00000)
+        # (the scores handed back are the candidates' own bits: the kernels never emit -0.0, keys.h folds it)
+        return np.ascontiguousarray(bits).view(np.float32), (top & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    key = sc + np.float32(0.0)
     # padding (row -1) must lose against a real row with the same score (-inf): row is the tie-break anyway
-    order = np.lexsort((rw, key), axis=-1)[:, ::-1][:, : max(k, 0)]
+    order = np.lexsort((rw, key), axis=-1)[:, ::-1][:, :k]
     return np.take_along_axis(sc, order, axis=1), np.take_along_axis(rw, order, axis=1)
 
 
@@ -200,7 +219,7 @@ class ShardedIndex:
              # the exchange has a stream of its own: issued on a search stream (rounds 1-3) that stream's next searches
              # sat behind the collective and the copy home -- ~120 us per exchange with one of two streams stalled,
              # 15 us per step at one GPU's share of the 8-GPU strong-scaling run (125 k rows: 0.131 -> see DESIGN 6)
-             "xstream": None if not self._multi else torch.cuda.Stream(device=dev)}
+             "xstream": None if not self._multi else torch.cuda.Stream(device=dev), "done": {}}
         self._pipe = p
 
     def _send_chunk(self, c: int, st) -> None:
@@ -218,6 +237,9 @@ class ShardedIndex:
             w.wait()    # orders this stream behind the collective; does not block the host
             if self.rank == self.dst:
                 p["host"][c].copy_(p["gathered"][c], non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(xs)
+                p["done"][c] = done          # chunk c is home when this fires (collect merges it while later chunks still run)
         p["sent"] = c + 1
 
     def enqueue(self, query_ptr: int, d: int) -> int:
@@ -247,19 +269,32 @@ class ShardedIndex:
         if self._multi and p["n"] > p["sent"] * g:
             last = p["n"] - 1
             self._send_chunk(last // g, p["streams"][last % len(p["streams"])])
-        torch.cuda.synchronize(self.device)
+        if self.rank != self.dst or not self._multi:
+            torch.cuda.synchronize(self.device)
         if self.rank != self.dst:
             return None
-        k, rec = p["k"], p["rec"]
+        k, rec, s_bytes = p["k"], p["rec"], p["s_bytes"]
         count = min(k, self.n_total)
         out = []
-        for i in range(first, p["n"]):
-            c, j = divmod(i, g)
-            sc, rw = unpack_records(p["host"][c].numpy()[:, j * rec:(j + 1) * rec], self.world, k)
-            if not self._multi:
+        if not self._multi:
+            for i in range(first, p["n"]):
+                c, j = divmod(i, g)
+                sc, rw = unpack_records(p["host"][c].numpy()[:, j * rec:(j + 1) * rec], self.world, k)
                 out.append((sc[0, :count].copy(), rw[0, :count].copy()))
-            else:
-                out.append(merge_topk(sc, rw, count))
+            return out
+        # chunk by chunk, in the order they come home: chunk c's records are merged (all its steps in one call)
+        # while the GPU is still searching for the later ones -- the host merge of 8 x 100 candidates per step
+        # (10 us; 56 us with the lexsort of rounds 1-3, serial, AFTER the last kernel: a third of an 8-GPU
+        # strong-scaling step) leaves the timed path except for the last chunk's
+        for c in range(first // g, (p["n"] + g - 1) // g):
+            p["done"][c].synchronize()
+            j0, j1 = max(first - c * g, 0), min(p["n"] - c * g, g)
+            buf = p["host"][c].numpy().reshape(self.world, g, rec)[:, j0:j1]
+            sc = np.ascontiguousarray(buf[:, :, :k * 4]).view(np.float32).reshape(self.world, j1 - j0, k)
+            rw = np.ascontiguousarray(buf[:, :, s_bytes:s_bytes + k * 8]).view(np.int64).reshape(self.world, j1 - j0, k)
+            ms, mr = merge_topk_batch(sc, rw, count)
+            out.extend((ms[j], mr[j]) for j in range(j1 - j0))
+        torch.cuda.synchronize(self.device)
         return out
 
     @property

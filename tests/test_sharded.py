@@ -84,6 +84,31 @@ def test_batched_merge_equals_per_query_merge():
         assert np.array_equal(mr, br[i]) and np.array_equal(ms, bs[i], equal_nan=True)
 
 
+def test_batched_merge_on_keys_and_on_lexsort_agree():
+    """merge_topk_batch orders rows below 2^32 by ONE sort of 64-bit keys (the kernels' own order key, csrc/keys.h) and
+    anything larger by a two-key lexsort: both must give merge_topk's answer on zeros of both signs, infinities,
+    denormals, NaN, ties across shards and padding -- 300 random tables each way."""
+    rng = np.random.default_rng(12)
+    vals = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, 0.5, np.nan, 2e-38, -3e-39, 0.25, 0.25], dtype=np.float32)
+    for trial in range(300):
+        g, nq, kk = int(rng.integers(1, 6)), int(rng.integers(1, 5)), int(rng.integers(1, 12))
+        sc = rng.choice(vals, size=(g, nq, kk))
+        rw = np.stack([rng.permutation(1000)[:nq * kk].reshape(nq, kk) + 1000 * i for i in range(g)]).astype(np.int64)
+        if trial % 2:
+            rw += (1 << 32)                   # the lexsort branch
+        pad = rng.random((g, nq, kk)) < 0.2
+        sc = np.where(pad, -np.inf, sc).astype(np.float32)
+        rw = np.where(pad, -1, rw)
+        k = int(min((rw >= 0).sum(axis=(0, 2)).min(), rng.integers(1, 20)))
+        if k == 0:
+            continue
+        bs, br = merge_topk_batch(sc, rw, k)
+        for i in range(nq):
+            ms, mr = merge_topk(sc[:, i, :], rw[:, i, :], k)
+            assert np.array_equal(mr, br[i]), (trial, i)
+            assert np.array_equal(ms + np.float32(0.0), bs[i] + np.float32(0.0), equal_nan=True), (trial, i)
+
+
 def test_record_of_a_query_batch():
     """A record holds the result of ONE call of nq queries: [nq*k scores | pad | nq*k rows]."""
     k, nq, world = 7, 5, 3
