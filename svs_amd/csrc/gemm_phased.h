@@ -750,6 +750,14 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
                       const uint32_t gs = __hip_atomic_fetch_add(hp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                       if (gs < fcap)
                         fcand[(int64_t)(t.q0 + ql) * fcap + gs] = ((uint64_t)score_key(v[r]) << 32) | (uint32_t)(pairs.row_base + t.row0 + lr0 + i * 16 + r);
+                      else if (fthr_stride)
+                        // The query's list is full: select_final will hand it back for a re-run whatever else arrives, so
+                        // its threshold goes to +inf -- the tiles that stage their thresholds after this store (every
+                        // workgroup's next one) park nothing for it.  Without this a corpus sorted by similarity to the
+                        // queries ran EVERY tile through this one-atomic-per-score path: 14 ms instead of 0.9 per 256
+                        // queries over 1M rows (tools/sorted_corpus_time.py).  (A stale read elsewhere is harmless: the
+                        // only difference is how many doomed candidates are still appended.)
+                        *(volatile float*)(fthr + (int64_t)(t.q0 + ql) * fthr_stride) = __builtin_inff();
                     }
                   }
                   wcount += __builtin_popcountll(mask[r]);

@@ -18,7 +18,8 @@ int32_t svs_internal_coalesce_hold(svs_index* idx, int32_t n);
 int32_t svs_internal_tune(int32_t what, int64_t value);
 /* Seconds since the start of the calling thread's last svs_index_search(host batch) at which: [0] scratch was planned,
  * [1] the queries were in pinned memory (and their DMA enqueued), [2] every kernel was enqueued, [3] the stream had
- * drained, [4] the results were in the caller's buffers. */
+ * drained, [4] the results were in the caller's buffers; [5] = the number of the call's queries whose fused candidate list
+ * overflowed and that were re-run through the materialised path (a count, not a time). */
 int32_t svs_internal_host_phases(double* out, int32_t n);
 /* multi.hip -> svs_amd.hip: carries a worker thread's error message over to the caller's thread */
 int32_t svs_internal_set_error(int32_t code, const char* msg);

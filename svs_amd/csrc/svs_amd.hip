@@ -83,6 +83,8 @@ struct Ctx {
   uint64_t* keys = nullptr;     size_t keys_cap = 0;     // u64
   float* q_pin = nullptr;       size_t q_pin_cap = 0;
   float* out_s_pin = nullptr;   int64_t* out_r_pin = nullptr; size_t out_pin_cap = 0;
+  float* redo_s_pin = nullptr;  int64_t* redo_r_pin = nullptr; size_t redo_pin_cap = 0;   // results of re-run queries (search_host)
+  float* redo_q_pin = nullptr;  size_t redo_q_cap = 0;                                      // ... and the queries themselves, gathered
   // Scratch is reused in stream order.  A context stays with the stream that
   // last used it; handing it to ANOTHER stream first drains the old one.
   hipStream_t last_stream = nullptr;
@@ -172,6 +174,9 @@ void ctx_destroy(Ctx* c) {
   (void)hipFree(c->q8s);
   (void)hipFree(c->pref_s);
   (void)hipFree(c->pref_r);
+  if (c->redo_q_pin) (void)hipHostFree(c->redo_q_pin);
+  if (c->redo_s_pin) (void)hipHostFree(c->redo_s_pin);
+  if (c->redo_r_pin) (void)hipHostFree(c->redo_r_pin);
   (void)hipFree(c->scores);
   (void)hipFree(c->hist);
   (void)hipFree(c->cand);
@@ -1709,18 +1714,53 @@ static int32_t search_host(svs_index* idx, const float* queries, int32_t nq, int
   }
   HIP_TRY(hipStreamSynchronize(c->stream));
   stamp(3);
-  // queries whose fused candidate list overflowed (marked row -2): exact re-run, one by one
-  for (int qi = 0; qi < nq; ++qi) {
-    if (c->out_r_pin[(size_t)qi * count] != -2) continue;
-    // (a pulled batch has no copy in HBM: the single-query kernels read their query many times, so it goes there first)
-    if (pull) HIP_TRY(hipMemcpyAsync(c->q_dev + (size_t)qi * d, c->q_pin + (size_t)qi * d, (size_t)d * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    if ((rc = enqueue_search(idx, c, c->q_dev + (size_t)qi * d, 1, count, count, c->out_s_pin + (size_t)qi * count,
-                             c->out_r_pin + (size_t)qi * count, c->stream, false)) != SVS_OK) {
+  // Queries whose fused candidate list overflowed (marked row -2; rows ordered by similarity to the query, so that the
+  // prefix's threshold cuts nothing): exact re-run through the MATERIALISED path, up to REDO_BATCH of them per pass.
+  // (Rounds 2-3 re-ran them one by one through the single-query kernels: 0.9 ms each at 1M rows, ~1 s for a 1024-query
+  //  batch over a corpus sorted that way, against 3 ms normally; in passes of 64 the same call took 55 ms, of 256: see
+  //  DESIGN 4.)  A pass's score matrix is kept under 2 GiB: 256 queries at 1M rows, 53 at 10M.
+  constexpr int REDO_BATCH = 256;
+  const int redo_max = (int)std::min<int64_t>(REDO_BATCH, std::max<int64_t>(1, ((int64_t)2 << 30) / (4 * std::max<int64_t>(idx->n, 1))));
+  int n_redo = 0;
+  for (int q0 = 0; q0 < nq;) {
+    int grp[REDO_BATCH], m = 0;
+    for (; q0 < nq && m < redo_max; ++q0)
+      if (c->out_r_pin[(size_t)q0 * count] == -2) grp[m++] = q0;
+    if (m == 0) break;
+    n_redo += m;
+    if ((size_t)REDO_BATCH * count > c->redo_pin_cap) {
+      if (c->redo_s_pin) HIP_TRY(hipHostFree(c->redo_s_pin));
+      if (c->redo_r_pin) HIP_TRY(hipHostFree(c->redo_r_pin));
+      c->redo_s_pin = nullptr; c->redo_r_pin = nullptr; c->redo_pin_cap = 0;
+      HIP_TRY(hipHostMalloc((void**)&c->redo_s_pin, (size_t)REDO_BATCH * count * sizeof(float), hipHostMallocDefault));
+      HIP_TRY(hipHostMalloc((void**)&c->redo_r_pin, (size_t)REDO_BATCH * count * sizeof(int64_t), hipHostMallocDefault));
+      c->redo_pin_cap = (size_t)REDO_BATCH * count;
+    }
+    // (the group's queries go to the front of q_dev in ONE copy -- whatever the main pass kept there is no longer needed,
+    //  the pinned buffer still holds every query of the call; a group that is not one run of queries is gathered first)
+    const float* src = c->q_pin + (size_t)grp[0] * d;
+    if (grp[m - 1] - grp[0] != m - 1) {
+      if ((size_t)REDO_BATCH * d > c->redo_q_cap) {
+        if (c->redo_q_pin) HIP_TRY(hipHostFree(c->redo_q_pin));
+        c->redo_q_pin = nullptr; c->redo_q_cap = 0;
+        HIP_TRY(hipHostMalloc((void**)&c->redo_q_pin, (size_t)REDO_BATCH * d * sizeof(float), hipHostMallocDefault));
+        c->redo_q_cap = (size_t)REDO_BATCH * d;
+      }
+      for (int j = 0; j < m; ++j) memcpy(c->redo_q_pin + (size_t)j * d, c->q_pin + (size_t)grp[j] * d, (size_t)d * sizeof(float));
+      src = c->redo_q_pin;
+    }
+    HIP_TRY(hipMemcpyAsync(c->q_dev, src, (size_t)m * d * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if ((rc = enqueue_search(idx, c, c->q_dev, m, count, count, c->redo_s_pin, c->redo_r_pin, c->stream, false)) != SVS_OK) {
       (void)hipStreamSynchronize(c->stream);
       return rc;
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int j = 0; j < m; ++j) {
+      memcpy(c->out_s_pin + (size_t)grp[j] * count, c->redo_s_pin + (size_t)j * count, (size_t)count * sizeof(float));
+      memcpy(c->out_r_pin + (size_t)grp[j] * count, c->redo_r_pin + (size_t)j * count, (size_t)count * sizeof(int64_t));
+    }
   }
+  g_host_phase[5] = (double)n_redo;   // (svs_internal_host_phases: queries of this call that were re-run)
   // device layout has stride `count`; the caller's has stride k
   if (count == k) {   // (one piece each)
     memcpy(out_scores, c->out_s_pin, on * sizeof(float));
@@ -2040,7 +2080,7 @@ int32_t svs_internal_tune(int32_t what, int64_t value) {
 }
 
 int32_t svs_internal_host_phases(double* out, int32_t n) {
-  for (int i = 0; i < n && i < 5; ++i) out[i] = g_host_phase[i];
+  for (int i = 0; i < n && i < 6; ++i) out[i] = g_host_phase[i];
   return SVS_OK;
 }
 
