@@ -99,3 +99,16 @@ def test_bench_config3_weak_and_multi_modes(gpu):
     multi = _bench_line(["--gpus", "2", "--multi", "--rows", "200000", "--steps", "10", "--warmup", "3"], {})
     assert multi["n_gpus"] == 2 and "svs_multi" in multi["config"]["path"] and multi["config"]["rows_per_shard"] == [100000, 100000]
     assert multi["value"] > 0
+
+
+def test_bench_rccl_exchange_path_with_the_one_rank_a_box_has(gpu):
+    """SVS_BENCH_FORCE_DIST=1: the N > 1 code path over the REAL backend (RCCL process group, records in HBM, the
+    all-gather + copy home on the exchange stream, chunk-by-chunk host merge on 64-bit keys) with one rank -- 29 steps,
+    so that the warm-up's partly filled chunk is re-sent and the last chunk is partial -- and every timed result checked
+    against the numpy oracle by bench.py's own spot check (the CPU baseline leg, 8 queries)."""
+    line = _bench_line(["--rows", "200000", "--steps", "29", "--warmup", "5", "--batch", "", "--concurrent", "0", "--configs", "",
+                        "--kb", "0", "--cpu-iters", "3"], {"SVS_BENCH_FORCE_DIST": "1"})
+    assert line["n_gpus"] == 1 and line["steps"] == 29 and line["config"]["steps_per_exchange"] == 8
+    assert line["config"]["searches_in_flight"] >= 2
+    assert line["parity_spot_check"] == {"queries": 8, "mismatches": 0}
+    assert line["value"] > 0
