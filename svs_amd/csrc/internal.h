@@ -14,7 +14,8 @@ int32_t svs_internal_coalesce_hold(svs_index* idx, int32_t n);
 /* Process-wide knobs for A/B measurements:
  *   0  fused path: threshold prefix = n / value rows (default 64; at least 16,384 rows)
  *   1  host batches: 0 = f16 batches pulled from pinned memory by the staging kernel, chunk by chunk (default);
- *      1 = staged DMA for every dtype (round 3) */
+ *      1 = staged DMA for every dtype (round 3)
+ *   2  fused path's threshold rows: 1 = a sample spread over the whole corpus (default); 0 = the first rows (rounds 1-3) */
 int32_t svs_internal_tune(int32_t what, int64_t value);
 /* Seconds since the start of the calling thread's last svs_index_search(host batch) at which: [0] scratch was planned,
  * [1] the queries were in pinned memory (and their DMA enqueued), [2] every kernel was enqueued, [3] the stream had

@@ -840,13 +840,21 @@ __global__ __launch_bounds__(256) void collect_pairs_kernel(
 // ---- tombstones (svs_index_mask_rows) ------------------------------------------
 // scores[q][row] = -inf for every masked (tombstoned) row
 // (rows >= n_rows are skipped: the fused path materialises only a prefix of the corpus)
+// blk_stride != 0: the score matrix is over the fused path's threshold SAMPLE -- blocks of 256 corpus rows taken every
+// blk_stride rows (svs_amd.hip prefix_image): corpus row r is sample row (r / blk_stride) * 256 + r % blk_stride if it
+// lies inside a block, and is not in the matrix otherwise.
 __global__ void mask_dead_rows_kernel(float* __restrict__ scores, int64_t sstride, int nq,
-                                      const uint32_t* __restrict__ dead, int64_t n_dead, int64_t n_rows) {
+                                      const uint32_t* __restrict__ dead, int64_t n_dead, int64_t n_rows, int64_t blk_stride) {
   const int64_t total = n_dead * nq;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
     const int64_t q = t / n_dead;
-    const uint32_t r = dead[t - q * n_dead];
-    if ((int64_t)r < n_rows) scores[q * sstride + r] = -__builtin_inff();
+    int64_t r = dead[t - q * n_dead];
+    if (blk_stride) {
+      const int64_t b = r / blk_stride, off = r - b * blk_stride;
+      if (off >= 256) continue;
+      r = b * 256 + off;
+    }
+    if (r < n_rows) scores[q * sstride + r] = -__builtin_inff();
   }
 }
 // pairwise matrix S[n][np]: whole row and column of a masked row -> -inf (masked rows >= n: the

@@ -56,3 +56,15 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
             json.dump(PARITY_SWAPS, f, indent=1)
     except OSError:
         pass
+
+
+@pytest.fixture
+def first_rows_thresholds():
+    """The fused batch path takes its thresholds from the FIRST rows of the corpus for the duration of the test (rounds
+    1-3's layout; svs_internal_tune(2, 0)), so that a corpus sorted by similarity to the queries still overflows the
+    candidate lists and the fallback paths stay under test.  The default -- a sample spread over the corpus -- is back after."""
+    from svs_amd import _native
+    lib = _native.load()
+    assert lib.svs_internal_tune(2, 0) == 0
+    yield
+    assert lib.svs_internal_tune(2, 1) == 0

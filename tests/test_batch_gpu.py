@@ -69,7 +69,7 @@ def test_batch_f32_fused_topk(gpu, kind, n, d, nq, k):
     idx.release()
 
 
-def test_batch_f32_fused_overflow_falls_back_exactly(gpu):
+def test_batch_f32_fused_overflow_falls_back_exactly(gpu, first_rows_thresholds):
     """Adversarial row order (scores rise with the row index): every row passes the
     prefix threshold, the candidate lists overflow, and those queries are re-run
     through the materialised path -- still exact."""

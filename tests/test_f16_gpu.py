@@ -89,7 +89,7 @@ def test_f16_large_batch_fused_topk(gpu, n, d, nq, k):
     idx.release()
 
 
-def test_f16_fused_overflow_falls_back_exactly(gpu):
+def test_f16_fused_overflow_falls_back_exactly(gpu, first_rows_thresholds):
     """Adversarial row order: scores rise with the row index, so every row passes
     the streaming cut and the candidate lists overflow; those queries must be
     re-run through the materialised path and still be exact."""
@@ -114,7 +114,7 @@ def test_f16_fused_overflow_falls_back_exactly(gpu):
     idx.release()
 
 
-def test_f16_a_whole_batch_of_overflowing_queries_is_rerun_in_batches(gpu):
+def test_f16_a_whole_batch_of_overflowing_queries_is_rerun_in_batches(gpu, first_rows_thresholds):
     """A corpus SORTED by similarity to the queries (every query's candidate list overflows): the host entry re-runs
     them through the materialised path, 64 per pass, not one single-query search each -- exact, and the call stays
     within a small multiple of an ordinary batch's time (rounds 2-3: one 0.2-0.9 ms search per query)."""
@@ -154,6 +154,46 @@ def test_f16_a_whole_batch_of_overflowing_queries_is_rerun_in_batches(gpu):
     assert ph[5] == 0
     print(f"all-overflow batch {dt * 1e3:.2f} ms ({n_rerun} re-run) vs ordinary batch {dt_plain * 1e3:.2f} ms")
     assert dt < 25 * dt_plain + 5e-3, (dt, dt_plain)
+    idx.release()
+
+
+@pytest.mark.parametrize("dtype,nq", [("f16", 200), ("f16", 16), ("f32", 16), ("fp8", 64)])
+def test_sorted_corpus_stays_on_the_fused_path(gpu, dtype, nq):
+    """The thresholds come from a sample spread over the whole corpus (blocks of 256 rows every n / 64 rows), so a
+    corpus SORTED by similarity to the queries is no worse than a shuffled one: nothing overflows, nothing is re-run,
+    the answers are exact -- also with the very best rows tombstoned, some of them inside the sample's blocks."""
+    import ctypes as C
+    from svs_amd import DeviceIndex, _native
+    rng = np.random.default_rng(21)
+    n, d, k = 150000, 128, 50
+    u = rng.standard_normal(d); u /= np.linalg.norm(u)
+    v = rng.standard_normal((n, d)); v -= np.outer(v @ u, u); v /= np.linalg.norm(v, axis=1, keepdims=True)
+    c = np.linspace(0.05, 0.95, n)[:, None]
+    m = (c * u[None, :] + np.sqrt(1 - c * c) * v).astype(np.float32)
+    qs = u[None, :] + 0.05 * rng.standard_normal((nq, d))
+    qs = (qs / np.linalg.norm(qs, axis=1, keepdims=True)).astype(np.float32)
+    idx = DeviceIndex(m, dtype=dtype)
+    md = m if dtype == "f32" else idx.stored_rows()
+    ph = (C.c_double * 6)()
+    dead = np.array([], dtype=np.int64)
+    for round_ in range(2):
+        bs, br = idx.search_batch(qs, k)
+        _native.load().svs_internal_host_phases(ph, 6)
+        assert ph[5] == 0, f"{int(ph[5])} queries were re-run: the thresholds cut too little"
+        for qi in (0, 1, nq // 2, nq - 1):
+            qd = qs[qi] if dtype == "f32" else idx.stored_query(qs[qi])
+            sc = oracle.cpu_scores_f64(md, qd)
+            if len(dead):
+                sc = sc.copy(); sc[dead] = -np.inf
+            order = np.lexsort((np.arange(n), sc))[::-1][:k]
+            assert not set(br[qi].tolist()) & set(dead.tolist())
+            assert_topk_parity(bs[qi], br[qi], sc[order].astype(np.float32), order.tolist(), sc, label=f"sorted corpus {dtype} q{qi} round {round_}",
+                               score_atol=1e-5 if dtype != "fp8" else 3e-4)
+        # second round: the best rows are tombstoned -- the last 300 of the corpus and the whole LAST BLOCK of the sample
+        # (64 blocks of 256 rows at this size, one every n // 64 rows): the thresholds must come from live rows only
+        stride = n // 64
+        dead = np.unique(np.r_[np.arange(n - 300, n), np.arange(63 * stride, 63 * stride + 256), np.arange(62 * stride + 100, 62 * stride + 130)])
+        idx.mask_rows(dead)
     idx.release()
 
 

@@ -1,5 +1,9 @@
 #!/usr/bin/env python3
-"""The fused batch path's worst case: a corpus SORTED by similarity to the queries (cosine to a direction u rises with
+"""A corpus SORTED by similarity to the queries (cosine to a direction u rises with the row index): with thresholds from
+the FIRST rows (rounds 1-3; `svs_internal_tune(2, 0)`, pass `first` as the fifth argument) they cut nothing, every candidate
+list of the fused batch path overflows and the host entry re-runs the queries through the materialised path; with the
+sample spread over the corpus (round 4's default) nothing overflows.  Prints the call time beside an ordinary batch of the
+same shape on the same index.  usage: sorted_corpus_time.py [n=1000000] [d=1536] [dtype=f16] [nq=1024] [first|spread]"""The fused batch path's worst case: a corpus SORTED by similarity to the queries (cosine to a direction u rises with
 the row index), so the threshold taken from the first rows cuts nothing, every candidate list overflows and the host
 entry re-runs the queries through the materialised path (64 per pass).  Prints the call time beside an ordinary batch
 of the same shape on the same index.  usage: sorted_corpus_time.py [n=1000000] [d=1536] [dtype=f16] [nq=1024]"""
@@ -18,6 +22,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 d = int(sys.argv[2]) if len(sys.argv) > 2 else 1536
 dtype = sys.argv[3] if len(sys.argv) > 3 else "f16"
 nq = int(sys.argv[4]) if len(sys.argv) > 4 else 1024
+layout = sys.argv[5] if len(sys.argv) > 5 else "spread"
+_native.load().svs_internal_tune(2, 0 if layout == "first" else 1)
 k = 100
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev)
@@ -40,7 +46,8 @@ qr = torch.randn((nq, d), device=dev, generator=g)
 qr = (qr / qr.norm(dim=1, keepdim=True)).cpu().numpy()
 ph = (C.c_double * 6)()
 lib = _native.load()
-for name, q in (("queries along u (every list overflows)", qa), ("random queries", qr)):
+print(f"thresholds from: {layout} rows")
+for name, q in (("queries along u", qa), ("random queries", qr)):
     idx.search_batch(q, k)
     t = []
     for _ in range(3):
