@@ -3,10 +3,7 @@
 the FIRST rows (rounds 1-3; `svs_internal_tune(2, 0)`, pass `first` as the fifth argument) they cut nothing, every candidate
 list of the fused batch path overflows and the host entry re-runs the queries through the materialised path; with the
 sample spread over the corpus (round 4's default) nothing overflows.  Prints the call time beside an ordinary batch of the
-same shape on the same index.  usage: sorted_corpus_time.py [n=1000000] [d=1536] [dtype=f16] [nq=1024] [first|spread]"""The fused batch path's worst case: a corpus SORTED by similarity to the queries (cosine to a direction u rises with
-the row index), so the threshold taken from the first rows cuts nothing, every candidate list overflows and the host
-entry re-runs the queries through the materialised path (64 per pass).  Prints the call time beside an ordinary batch
-of the same shape on the same index.  usage: sorted_corpus_time.py [n=1000000] [d=1536] [dtype=f16] [nq=1024]"""
+same shape on the same index.  usage: sorted_corpus_time.py [n=1000000] [d=1536] [dtype=f16] [nq=1024] [first|spread]"""
 import ctypes as C
 import os
 import sys
