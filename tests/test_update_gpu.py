@@ -233,3 +233,49 @@ def test_scores_after_append_through_another_owner(gpu):
     assert rc == _native.SVS_ERR_INVALID and now.value == 9000 and (buf == 7.0).all()
     other.release()
     idx.release()
+
+
+def test_append_while_fused_batches_run(gpu):
+    """Rows are appended (the fused path's threshold sample is re-taken after every append: svs_amd.hip prefix_image)
+    while three threads keep 16-query batches on the fused path in flight: every answer must be a real, distinct set of
+    rows of the final matrix with those rows' own scores, best first -- for whichever row count the search saw -- and
+    once the appends are done the answers equal a fresh index over everything."""
+    from svs_amd import DeviceIndex
+    rng = np.random.default_rng(33)
+    n0, n1, d, nq, k = 140000, 200000, 128, 16, 40
+    m = rng.standard_normal((n1, d)).astype(np.float32)
+    m /= np.linalg.norm(m, axis=1, keepdims=True)
+    qs = rng.standard_normal((nq, d)).astype(np.float32)
+    qs /= np.linalg.norm(qs, axis=1, keepdims=True)
+    idx = DeviceIndex.empty(d, reserve=n0)          # (no room reserved for the appends: the buffers are re-allocated too)
+    idx.append(m[:n0])
+    errs, stop = [], threading.Event()
+
+    def searcher():
+        try:
+            while not stop.is_set():
+                bs, br = idx.search_batch(qs, k)
+                assert br.shape == (nq, k) and (br >= 0).all() and (br < n1).all()
+                for qi in (0, nq - 1):
+                    rows = br[qi]
+                    assert len(set(rows.tolist())) == k
+                    assert np.abs(m[rows].astype(np.float64) @ qs[qi].astype(np.float64) - bs[qi]).max() < 1e-5
+                    assert (np.diff(bs[qi].astype(np.float64)) <= 0).all()
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=searcher) for _ in range(3)]
+    for t in ts:
+        t.start()
+    for c0 in range(n0, n1, 6000):
+        idx.append(m[c0:c0 + 6000])
+    stop.set()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    full = DeviceIndex(m)
+    bs, br = idx.search_batch(qs, k)
+    fs, fr = full.search_batch(qs, k)
+    assert np.array_equal(br, fr) and np.array_equal(bs, fs)
+    full.release()
+    idx.release()
