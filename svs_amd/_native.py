@@ -11,7 +11,8 @@ import ctypes as C
 import os
 from typing import Optional
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libsvs_amd.so")
+# (SVS_AMD_LIB: another build of the same library, for same-box A/B runs of tools/)
+_LIB_PATH = os.environ.get("SVS_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libsvs_amd.so")
 
 SVS_OK = 0
 SVS_ERR_INVALID = -1

@@ -251,7 +251,9 @@ __device__ __forceinline__ void pg_landed_b(u32x4 (&fb)[1][2]) {
 #ifdef PG_TRACE
 constexpr int PG_PARK = 512;      // (trace builds keep their stamps behind the side region)
 #else
-constexpr int PG_PARK = 1024;     // candidates a workgroup can park per tile (~420 expected at k = 100, prefix n / 64)
+constexpr int PG_PARK = 1536;     // candidates a workgroup can park per tile (~420 expected at k = 100, prefix n / 64): 192 per wave.  (1024 through round 3: a
+                                  // corpus stored topic by topic puts one query's 128 survivors into ONE wave's 128 rows, plus ~50 of the others': every such
+                                  // wave overflowed into the one-atomic-per-candidate path -- tools/clustered_corpus_time.py)
 #endif
 constexpr int PG_SIDE = PG_LDS_BYTES;                   // byte offsets
 constexpr int PG_SIDE_THR = PG_SIDE;                    // f32 [2][256]
@@ -259,8 +261,10 @@ constexpr int PG_SIDE_RS = PG_SIDE_THR + 2048;          // f32 [2][256] row scal
 constexpr int PG_SIDE_QS = PG_SIDE_RS + 2048;           // f32 [2][256] query scales (fp8)
 constexpr int PG_SIDE_CNT = PG_SIDE_QS + 2048;          // u32 [2][8]: candidates parked by each wave
 constexpr int PG_SIDE_KEY = PG_SIDE_CNT + 64;           // u32 [2][PG_PARK][2]: (score bits, code); wave w owns entries [w * PG_PARK / 8, ..)
-constexpr int PG_LDS_TOTAL = PG_SIDE_KEY + 2 * PG_PARK * 8;  // 153,664 bytes of the 163,840
+constexpr int PG_LDS_TOTAL = PG_SIDE_KEY + 2 * PG_PARK * 8;  // 161,856 bytes of the 163,840
+static_assert(PG_LDS_TOTAL <= 160 * 1024 && PG_PARK % PG_THREADS == 0 && PG_PARK % 8 == 0, "the parking lot must fit the LDS, in whole rounds of the flush loops");
 // a parked candidate's code: row inside the tile (8 bits) | query inside the tile << 8
+constexpr int PG_AGG_MIN = 96;     // candidates parked by a wave from which its flush adds per RUN of a query (flush_group): a shuffled corpus parks ~52 +- 7
 constexpr int PG_SPARSE_MAX = 16;  // survivors per wave and tile up to which the epilogue compares-and-branches per group of four registers
                                    // (~150 cycles per group that holds one: at 16 still below the sweeps' fixed 10-11 k cycles per tile)
 constexpr int PG_FLUSH_KT = 2, PG_MIN_KT = 6;   // the flush brackets k-tiles 2 and 3 of the next tile
@@ -588,7 +592,9 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
   // ---- flush of the candidates parked by the PREVIOUS tile (copy pp, queries pq0 ..): step A
   // issues one returning global atomic per candidate (slot in the query's list), step B -- four
   // k-tiles = 32 counted vmcnt waits later -- stores the keys
-  uint32_t fslot[2] = {0u, 0u};
+  constexpr int PG_FSLOTS = PG_PARK / PG_THREADS;   // parked entries a thread flushes per tile
+  static_assert(PG_FSLOTS == 3 || PG_FSLOTS == 1, "flush_b's waits name the slot registers one by one");
+  uint32_t fslot[3] = {0u, 0u, 0u};
   int last_wcount = PG_SPARSE_MAX + 1;   // survivors this wave parked in its previous tile (wave-uniform; the first tile takes the sweeps)
   int f_pp = 0, f_q0 = 0;     // wave-uniform
   int64_t f_row0 = 0;
@@ -596,42 +602,101 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
   //  tile -- a handful of ALU instructions -- instead of being computed once, kept live across the k loop and,
   //  the register file being full there, spilled: every reload of a spilled VGPR waits vmcnt(0), i.e. for the
   //  whole LDS-DMA ring)
+  // One atomic per RUN of a query, not per candidate: the sweeps park lane by lane, so the 32 rows a lane holds for one
+  // query sit in consecutive entries, and a corpus stored topic by topic fills whole runs with ONE query (every row of a
+  // tile a neighbour of the same few queries).  All 256 workgroups are then on that topic's tiles at the same moment, and
+  // one atomic per candidate put ~400 of them per tile on the same 32 counters: their latency, no longer covered by two
+  // k-tiles, came out at the counted waits (1M x 1536 f16 in 32 / 256 topics: 3.6 / 4.5 ms of score stage against 2.9
+  // shuffled; the materialised path, which has no flush, 3.2 whatever the order).  Each round of 64 entries takes the
+  // query of its first live entry, counts the lanes that share it (a ballot) and lets the first of them add that count;
+  // the others add for themselves as before.  flush_b recomputes the same grouping from the same LDS words instead of
+  // keeping it in registers across the two k-tiles in between.  Only waves that parked PG_AGG_MIN candidates or more do any of
+  // this: the ordinary tile (a shuffled corpus parks ~52 per wave) keeps round 3's flush, instruction for instruction -- with
+  // the grouping on every tile configs[2]'s kernel was 0-6 % slower by box (same-box A/B, tools/ab_before_after.sh).
+  // (a second run per round -- a lane that holds two of the topic's queries parks them alternately -- was measured too:
+  //  no further gain, 3.4-3.6 ms either way)
+  auto flush_group = [&](bool valid, int q, int* first, unsigned long long* same) __attribute__((always_inline)) -> bool {
+    const unsigned long long vm = __ballot(valid);
+    if (vm == 0) return false;   // (wave-uniform)
+    *first = (int)__builtin_ctzll(vm);
+    const int q0 = __builtin_amdgcn_readlane(q, *first);
+    *same = __ballot(valid && q == q0);
+    return true;
+  };
   auto flush_a = [&]() __attribute__((always_inline)) {
     int tid = (int)threadIdx.x;
     asm volatile("" : "+v"(tid));
+    const int lane_f = tid & 63;
 #pragma unroll
     for (int r = 0; r < PG_PARK / PG_THREADS; ++r) {
       const int e = tid + r * PG_THREADS, w = e / (PG_PARK / 8), i = e % (PG_PARK / 8);
       const uint32_t nw = pg_lds_read_u32(PG_SIDE_CNT + (f_pp * 8 + w) * 4);
-      if ((uint32_t)i < nw) {
-        const uint32_t code = pg_lds_read_u32(PG_SIDE_KEY + (f_pp * PG_PARK + e) * 8 + 4);
-        // (a padded query of the last query tile can park a candidate only through a NaN score -- its threshold is
-        //  +inf -- and has no list: dropped here and in flush_b)
-        if (f_q0 + (int)(code >> 8) >= nq) continue;
-        uint32_t* p = fstate_words + (int64_t)(f_q0 + (int)(code >> 8)) * fstate_stride;
-        const uint32_t one = 1u;
-        asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(fslot[r]) : "v"(p), "v"(one) : "memory");
+      // (ONE asm site per round for both forms: the atomic's result register is written when the atomic RETURNS, long
+      //  after the asm statement -- with a site in each branch hipcc joined the two results through a copy made right
+      //  behind the asm, i.e. of a register the atomic had not written yet)
+      bool issue;
+      uint32_t add = 1u;
+      int q = 0;
+      if (__builtin_amdgcn_readfirstlane((int)nw) < PG_AGG_MIN) {   // (the ordinary tile: one atomic per candidate, no grouping in the k loop)
+        issue = (uint32_t)i < nw;
+        if (issue) {
+          q = (int)(pg_lds_read_u32(PG_SIDE_KEY + (f_pp * PG_PARK + e) * 8 + 4) >> 8);
+          // (a padded query of the last query tile can park a candidate only through a NaN score -- its threshold is
+          //  +inf -- and has no list: dropped here and in flush_b)
+          issue = f_q0 + q < nq;
+        }
+      } else {
+        q = (int)(pg_lds_read_u32(PG_SIDE_KEY + (f_pp * PG_PARK + e) * 8 + 4) >> 8);
+        const bool valid = (uint32_t)i < nw && f_q0 + q < nq;
+        int first = 0;
+        unsigned long long same = 0;
+        const bool any = flush_group(valid, q, &first, &same);
+        const bool in_run = ((same >> lane_f) & 1ull) != 0;
+        issue = any && valid && (!in_run || lane_f == first);
+        add = in_run ? (uint32_t)__builtin_popcountll(same) : 1u;
+      }
+      if (issue) {
+        uint32_t* p = fstate_words + (int64_t)(f_q0 + q) * fstate_stride;
+        asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(fslot[r]) : "v"(p), "v"(add) : "memory");
       }
     }
   };
   // drain == false: the caller guarantees that at least PG_VMCNT vector-memory instructions were issued after
   // flush_a's atomics (see the invariant at the call site in the k loop); drain == true: wait for everything
   auto flush_b = [&](bool drain) __attribute__((always_inline)) {
-    if (!drain) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(fslot[0]), "+v"(fslot[1]) : "n"(PG_VMCNT) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(fslot[0]), "+v"(fslot[1])::"memory");
+    if (!drain) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(fslot[0]), "+v"(fslot[1]), "+v"(fslot[2]) : "n"(PG_VMCNT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(fslot[0]), "+v"(fslot[1]), "+v"(fslot[2])::"memory");
     int tid = (int)threadIdx.x;
     asm volatile("" : "+v"(tid));
+    const int lane_f = tid & 63;
 #pragma unroll
     for (int r = 0; r < PG_PARK / PG_THREADS; ++r) {
       const int e = tid + r * PG_THREADS, w = e / (PG_PARK / 8), i = e % (PG_PARK / 8);
       const uint32_t nw = pg_lds_read_u32(PG_SIDE_CNT + (f_pp * 8 + w) * 4);
-      if ((uint32_t)i < nw && fslot[r] < fcap) {
-        const uint64_t sc = pg_lds_read_u64(PG_SIDE_KEY + (f_pp * PG_PARK + e) * 8);   // (score bits, code)
-        const uint32_t code = (uint32_t)(sc >> 32);
-        if (f_q0 + (int)(code >> 8) >= nq) continue;
-        fcand[(int64_t)(f_q0 + (int)(code >> 8)) * fcap + fslot[r]] =
-            ((uint64_t)score_key(__builtin_bit_cast(float, (uint32_t)sc)) << 32) | (uint32_t)(pairs.row_base + f_row0 + (code & 255u));
+      if (__builtin_amdgcn_readfirstlane((int)nw) < PG_AGG_MIN) {   // (as flush_a decided, from the same word)
+        if ((uint32_t)i < nw && fslot[r] < fcap) {
+          const uint64_t sc = pg_lds_read_u64(PG_SIDE_KEY + (f_pp * PG_PARK + e) * 8);   // (score bits, code)
+          const uint32_t code = (uint32_t)(sc >> 32);
+          if (f_q0 + (int)(code >> 8) >= nq) continue;
+          fcand[(int64_t)(f_q0 + (int)(code >> 8)) * fcap + fslot[r]] =
+              ((uint64_t)score_key(__builtin_bit_cast(float, (uint32_t)sc)) << 32) | (uint32_t)(pairs.row_base + f_row0 + (code & 255u));
+        }
+        continue;
       }
+      const uint64_t sc = pg_lds_read_u64(PG_SIDE_KEY + (f_pp * PG_PARK + e) * 8);   // (score bits, code)
+      const uint32_t code = (uint32_t)(sc >> 32);
+      const int q = (int)(code >> 8);
+      const bool valid = (uint32_t)i < nw && f_q0 + q < nq;
+      int first;
+      unsigned long long same;
+      if (!flush_group(valid, q, &first, &same)) continue;
+      // (the run's base came back to its first lane; a lane's place in the run is its rank inside the mask)
+      const uint32_t run_base = (uint32_t)__builtin_amdgcn_readlane((int)fslot[r], first);
+      const bool in_run = ((same >> lane_f) & 1ull) != 0;
+      const uint32_t slot = in_run ? run_base + __builtin_amdgcn_mbcnt_hi((uint32_t)(same >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)same, 0u)) : fslot[r];
+      if (valid && slot < fcap)
+        fcand[(int64_t)(f_q0 + q) * fcap + slot] =
+            ((uint64_t)score_key(__builtin_bit_cast(float, (uint32_t)sc)) << 32) | (uint32_t)(pairs.row_base + f_row0 + (code & 255u));
     }
   };
 

@@ -91,9 +91,25 @@ def test_no_ring_drain_between_tile_loop_header_and_k_loop(build_reports):
         drains = [l.strip() for l in stretch if re.search(r"s_waitcnt.*vmcnt\(0\)", l)]
         assert not drains, f"{pretty}: {len(drains)} ring-draining waits before the k loop"
         # the k loop itself: counted waits only
-        loop_end = next(i for i in range(inner, len(body)) if re.search(r"s_cbranch_\w+ \.LBB\d+_\d+", body[i]) and i > inner + 200)
-        mfma = [l for l in body[inner:loop_end] if "v_mfma" in l]
+        # (the loop's blocks are the ones hipcc annotates with its header -- they need not be contiguous, the latch sits ABOVE
+        #  the header, and wave-uniform branches inside the loop, the flush of the previous tile's candidates has some, end nothing)
+        hdr_line = next(i for i in range(inner, max(inner - 6, 0), -1) if re.match(r"\.LBB\d+_\d+:", body[i]))
+        hdr = re.match(r"\.L(BB\d+_\d+):", body[hdr_line]).group(1)
+        mfma, loop_drains, cur_in = [], [], False
+        for i, l in enumerate(body):
+            if re.match(r"\.LBB\d+_\d+:", l):
+                j, head = i + 1, l
+                while j < len(body) and re.match(r"\s+;", body[j]):
+                    head += body[j]
+                    j += 1
+                cur_in = i == hdr_line or f"Header={hdr} Depth=2" in head
+            if cur_in and "v_mfma" in l:
+                mfma.append(l)
+            if cur_in and re.search(r"s_waitcnt.*vmcnt\(0\)", l):
+                loop_drains.append(l.strip())
         assert len(mfma) >= 32, f"{pretty}: {len(mfma)} MFMAs in what should be the k loop (two k-tiles: 32 at fp8 128-query tiles .. 128 at f16 256-query tiles)"
+        if re.search(r"gemm_phased_kernel<true, [12], (0|20), ", pretty):   # the shipped forms: nothing in the loop drains the LDS-DMA ring
+            assert not loop_drains, f"{pretty}: {len(loop_drains)} vmcnt(0) waits inside the k loop"
         checked += 1
     assert checked >= 10
 

@@ -42,6 +42,8 @@ q = (q / q.norm(dim=1, keepdim=True)).cpu().numpy()
 ph = (C.c_double * 6)()
 lib = _native.load()
 res = {}
+if os.environ.get("CCT_VARIANT"):          # e.g. CCT_VARIANT=6: the materialised path (no fused epilogue) on the same data
+    idx.set_variant(int(os.environ["CCT_VARIANT"]))
 for layout in ("first", "spread"):
     lib.svs_internal_tune(2, 0 if layout == "first" else 1)
     idx.search_batch(q, k)
