@@ -42,6 +42,8 @@ q = (q / q.norm(dim=1, keepdim=True)).cpu().numpy()
 ph = (C.c_double * 6)()
 lib = _native.load()
 res = {}
+if os.environ.get("CCT_DIV"):              # threshold sample of n / CCT_DIV rows (default 64)
+    lib.svs_internal_tune(0, int(os.environ["CCT_DIV"]))
 if os.environ.get("CCT_VARIANT"):          # e.g. CCT_VARIANT=6: the materialised path (no fused epilogue) on the same data
     idx.set_variant(int(os.environ["CCT_VARIANT"]))
 for layout in ("first", "spread"):
