@@ -265,6 +265,8 @@ constexpr int PG_LDS_TOTAL = PG_SIDE_KEY + 2 * PG_PARK * 8;  // 161,856 bytes of
 static_assert(PG_LDS_TOTAL <= 160 * 1024 && PG_PARK % PG_THREADS == 0 && PG_PARK % 8 == 0, "the parking lot must fit the LDS, in whole rounds of the flush loops");
 // a parked candidate's code: row inside the tile (8 bits) | query inside the tile << 8
 constexpr int PG_AGG_MIN = 96;     // candidates parked by a wave from which its flush adds per RUN of a query (flush_group): a shuffled corpus parks ~52 +- 7
+constexpr int PG_FEW_DENSE = 8;    // ... or a wave on the compare-and-branch path (it expected <= PG_SPARSE_MAX survivors and counts no lanes) that parked this many
+constexpr int PG_LANE_DENSE = 6;   // ... or survivors of ONE lane (the sweeps count them): few queries per topic put few candidates into a wave, all of one query
 constexpr int PG_SPARSE_MAX = 16;  // survivors per wave and tile up to which the epilogue compares-and-branches per group of four registers
                                    // (~150 cycles per group that holds one: at 16 still below the sweeps' fixed 10-11 k cycles per tile)
 constexpr int PG_FLUSH_KT = 2, PG_MIN_KT = 6;   // the flush brackets k-tiles 2 and 3 of the next tile
@@ -630,14 +632,14 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
 #pragma unroll
     for (int r = 0; r < PG_PARK / PG_THREADS; ++r) {
       const int e = tid + r * PG_THREADS, w = e / (PG_PARK / 8), i = e % (PG_PARK / 8);
-      const uint32_t nw = pg_lds_read_u32(PG_SIDE_CNT + (f_pp * 8 + w) * 4);
+      const uint32_t nwf = pg_lds_read_u32(PG_SIDE_CNT + (f_pp * 8 + w) * 4), nw = nwf & 0x7fffffffu;   // (bit 31: flush by runs, set by the epilogue)
       // (ONE asm site per round for both forms: the atomic's result register is written when the atomic RETURNS, long
       //  after the asm statement -- with a site in each branch hipcc joined the two results through a copy made right
       //  behind the asm, i.e. of a register the atomic had not written yet)
       bool issue;
       uint32_t add = 1u;
       int q = 0;
-      if (__builtin_amdgcn_readfirstlane((int)nw) < PG_AGG_MIN) {   // (the ordinary tile: one atomic per candidate, no grouping in the k loop)
+      if (__builtin_amdgcn_readfirstlane((int)nwf) >= 0) {   // (the ordinary tile: one atomic per candidate, no grouping in the k loop)
         issue = (uint32_t)i < nw;
         if (issue) {
           q = (int)(pg_lds_read_u32(PG_SIDE_KEY + (f_pp * PG_PARK + e) * 8 + 4) >> 8);
@@ -672,8 +674,8 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
 #pragma unroll
     for (int r = 0; r < PG_PARK / PG_THREADS; ++r) {
       const int e = tid + r * PG_THREADS, w = e / (PG_PARK / 8), i = e % (PG_PARK / 8);
-      const uint32_t nw = pg_lds_read_u32(PG_SIDE_CNT + (f_pp * 8 + w) * 4);
-      if (__builtin_amdgcn_readfirstlane((int)nw) < PG_AGG_MIN) {   // (as flush_a decided, from the same word)
+      const uint32_t nwf = pg_lds_read_u32(PG_SIDE_CNT + (f_pp * 8 + w) * 4), nw = nwf & 0x7fffffffu;
+      if (__builtin_amdgcn_readfirstlane((int)nwf) >= 0) {   // (as flush_a decided, from the same word)
         if ((uint32_t)i < nw && fslot[r] < fcap) {
           const uint64_t sc = pg_lds_read_u64(PG_SIDE_KEY + (f_pp * PG_PARK + e) * 8);   // (score bits, code)
           const uint32_t code = (uint32_t)(sc >> 32);
@@ -840,6 +842,7 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
       // slots in the wave's eighth, (3) a second sweep parks them: v_cmpx makes the survivors the
       // active lanes, they store (score, code) and step their address, exec is restored -- five
       // instructions per register, the same whatever survives.
+      bool w_dense = false, w_few = false;   // (wave-uniform)
       auto sweep = [&]() __attribute__((always_inline)) -> bool {   // true: more survivors than the wave's eighth holds, nothing parked
         float thr[NT];
         uint32_t base[NT];
@@ -864,6 +867,9 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r) cnt += !(val(i, j, r) < thr[j]) ? 1u : 0u;   // (a NaN passes)
         }
+        // (a lane -- 32 rows x 4 queries -- with PG_LANE_DENSE survivors or more has met one of its queries' own topic: the
+        //  wave's flush goes by runs.  A shuffled corpus gives a lane 0.8 on average: one wave in a hundred says so.)
+        w_dense = __ballot(cnt >= (uint32_t)PG_LANE_DENSE) != 0;
         // inclusive scan over the wave: four row shifts, then the two row broadcasts
         uint32_t x = cnt;
         x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);
@@ -908,6 +914,7 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
         // (a partly filled last QUERY tile is an interior tile too: the sweeps give its padded queries +inf
         //  thresholds; only the grouped path needs the per-lane query mask, i.e. the general form of pass())
         const bool few = last_wcount <= PG_SPARSE_MAX;
+        w_few = few;
         if (few) {
           if (t.q0 + QT <= nq) grouped_full = true;
           else general = true;
@@ -919,7 +926,8 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
       if (grouped_full) pass(std::true_type{}, std::true_type{});
       if (general) pass(std::false_type{}, std::false_type{});
       last_wcount = EXP == 32 ? PG_SPARSE_MAX + 1 : wcount;   // (EXP 32: the sweeps on every interior tile, A/B)
-      if (lane == 0) pg_lds_write_u32(PG_SIDE_CNT + (par * 8 + wave) * 4, (uint32_t)(wcount < WCAP ? wcount : WCAP));
+      if (lane == 0)
+        pg_lds_write_u32(PG_SIDE_CNT + (par * 8 + wave) * 4, (uint32_t)(wcount < WCAP ? wcount : WCAP) | ((w_dense || wcount >= PG_AGG_MIN || (w_few && wcount >= PG_FEW_DENSE)) ? 0x80000000u : 0u));
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // parked entries written before this wave's next barrier
     }
   };
