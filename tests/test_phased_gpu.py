@@ -148,6 +148,39 @@ def test_phased_clustered_rows_overflow_the_parking_lot(gpu, dtype):
     idx.release()
 
 
+@pytest.mark.parametrize("dtype,k", [("f16", 100), ("f16", 8), ("fp8", 8)])
+def test_phased_small_topics_flush_by_runs(gpu, dtype, k):
+    """Topics of a few dozen rows: a wave parks FEW candidates in such a tile, all of one query -- the flush then adds per
+    run of a query instead of per candidate (gemm_phased.h flush_group), switched on by one lane's survivor count (k = 100:
+    the sweeps count per lane) or by what a wave on the compare-and-branch path parked (k = 8: it expected almost none).
+    Several topics per tile, topics across tile and wave boundaries, two topics of the same query; the oracle's answer, and
+    the round-1 kernel's bit for bit."""
+    from svs_amd import DeviceIndex
+    n, d, nq = 150000, 512 if dtype == "f16" else 1024, 200
+    m, qs = corpus_and_query("gaussian", 777, n, d, nq)
+    rng = np.random.default_rng(10)
+    topics = ((90000, 40, 7), (90100, 24, 9), (90240, 40, 11), (120000 + 250, 12, 13), (256 * 300 + 120, 16, 7), (33, 60, 190))
+    for base, cnt, qi in topics:
+        noise = rng.standard_normal((cnt, d)).astype(np.float32) * np.float32(0.15 / np.sqrt(d))
+        rows = qs[qi][None, :] + noise
+        m[base:base + cnt] = rows / np.linalg.norm(rows, axis=1, keepdims=True)
+    idx = DeviceIndex(m, dtype=dtype)
+    s0, r0 = idx.search_batch(qs, k)
+    idx.set_variant(2)
+    s2, r2 = idx.search_batch(qs, k)
+    idx.set_variant(0)
+    assert np.array_equal(r0, r2) and np.array_equal(s0, s2)
+    md = idx.stored_rows()
+    for qi in (7, 9, 11, 13, 190, 0, 199):
+        qd = idx.stored_query(qs[qi])
+        exp = oracle.cpu_search(md, qd, k)
+        assert_topk_parity(s0[qi], r0[qi], [s for s, _ in exp], [i for _, i in exp],
+                           oracle.cpu_scores_f64(md, qd), label=f"small topics {dtype} k={k} q{qi}")
+    own = set(range(90000, 90040)) | set(range(256 * 300 + 120, 256 * 300 + 136))
+    assert set(r0[7][:min(k, 56)]) <= own
+    idx.release()
+
+
 def test_phased_kernel_rate_floor(gpu):
     """A tripwire, not a benchmark: the fused f16 panel kernel must run above 500 TFLOP/s (it measures
     ~1,250).  hipcc has twice turned a small source change into accumulators kept in scratch memory or
