@@ -381,11 +381,31 @@ __global__ __launch_bounds__(PG_THREADS) void gemm_phased_kernel(
     adrB[h] = (unsigned)(((wc * (16 * NTQ) + r16) * 8 + ((4 * h + g) ^ tg_swz(r16))) * 16);
   }
 
+  // Row tiles are taken in a SCATTERED order (fused form): row tile bx of the schedule is row tile (bx * perm_s) mod gx of
+  // the corpus, perm_s a prime that does not divide gx (1,009 row tiles = 258 k rows apart at 1M rows).  In schedule order the 256 workgroups sit on 64-256 NEIGHBOURING row
+  // tiles at any moment; in a corpus stored topic by topic those belong to one or two topics, and every workgroup's
+  // candidates of the moment go to the lists of the same few queries (their counters, their next free cache lines).
+  // Scattered, the tiles in flight are a sample of the whole corpus, as they are for a shuffled one.  (The query tiles of
+  // a row tile keep their place: same XCD, adjacent in time.)
+  int perm_s = 1;
+  if constexpr (FUSE && kMap == 0) {
+    // (a prime that does not divide gx is coprime to it; the first of a fixed list that leaves at least two strides: no loop)
+    const int sgx = __builtin_amdgcn_readfirstlane(gx);
+    int c = 1;
+    if (sgx > 2 * 3 && sgx % 3) c = 3;
+    if (sgx > 2 * 7 && sgx % 7) c = 7;
+    if (sgx > 2 * 31 && sgx % 31) c = 31;
+    if (sgx > 2 * 127 && sgx % 127) c = 127;
+    if (sgx > 2 * 1009 && sgx % 1009) c = 1009;
+    if (sgx > 2 * 7919 && sgx % 7919) c = 7919;
+    perm_s = __builtin_amdgcn_readfirstlane(c);
+  }
   auto tile_desc = [&](int j) __attribute__((always_inline)) {
     PgTile t;
     if (j < my_tiles) {
       int bx, by;
       pg_tile_of((int)blockIdx.x + j * G, gx, gy, &bx, &by);
+      if constexpr (FUSE && kMap == 0) bx = (int)(((long long)bx * perm_s) % gx);
       if (alt_map) {
         const int x = (int)blockIdx.x & 7, c = (int)blockIdx.x >> 3;
         if (kMap == 1) { by = x & 3; bx = (j * 32 + c) * 2 + (x >> 2); }
