@@ -82,7 +82,20 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void gemm_f32_q16_kernel(
   }
   __syncthreads();
 
-  const int64_t blk0 = (int64_t)blockIdx.x * rows_per_block;
+  // (fused form: the row blocks are taken in a scattered order, as the phased kernel takes its row tiles -- gemm_phased.h tile_desc:
+  //  neighbouring blocks of a corpus stored topic by topic send all their candidates to the lists of the same few queries)
+  int64_t pblk = blockIdx.x;
+  if constexpr (FUSE) {
+    const int g_ = (int)gridDim.x;
+    int c = 1;
+    if (g_ > 2 * 3 && g_ % 3) c = 3;
+    if (g_ > 2 * 7 && g_ % 7) c = 7;
+    if (g_ > 2 * 31 && g_ % 31) c = 31;
+    if (g_ > 2 * 127 && g_ % 127) c = 127;
+    if (g_ > 2 * 1009 && g_ % 1009) c = 1009;
+    pblk = (pblk * c) % g_;
+  }
+  const int64_t blk0 = pblk * rows_per_block;
   const int64_t blk1 = blk0 + rows_per_block < n ? blk0 + rows_per_block : n;
   const int r16 = lane & 15, g = lane >> 4;
   constexpr int TROWS = 16 * TILES;
@@ -259,7 +272,20 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void gemm_q16r_kernel(
   }
   __syncthreads();
 
-  const int64_t blk0 = (int64_t)blockIdx.x * rows_per_block;
+  // (fused form: the row blocks are taken in a scattered order, as the phased kernel takes its row tiles -- gemm_phased.h tile_desc:
+  //  neighbouring blocks of a corpus stored topic by topic send all their candidates to the lists of the same few queries)
+  int64_t pblk = blockIdx.x;
+  if constexpr (FUSE) {
+    const int g_ = (int)gridDim.x;
+    int c = 1;
+    if (g_ > 2 * 3 && g_ % 3) c = 3;
+    if (g_ > 2 * 7 && g_ % 7) c = 7;
+    if (g_ > 2 * 31 && g_ % 31) c = 31;
+    if (g_ > 2 * 127 && g_ % 127) c = 127;
+    if (g_ > 2 * 1009 && g_ % 1009) c = 1009;
+    pblk = (pblk * c) % g_;
+  }
+  const int64_t blk0 = pblk * rows_per_block;
   const int64_t blk1 = blk0 + rows_per_block < n ? blk0 + rows_per_block : n;
   const int i4 = lane & 3, b = lane >> 2;
   constexpr int TROWS = 4 * RG;
